@@ -1,0 +1,193 @@
+/*
+ * rerank_mi355.h — C ABI of librerank_mi355.so
+ *
+ * MI355X (gfx950) native cross-encoder rerank forward: the batched
+ * (query x K-candidate) BERT-style encoder, the 128-d late-interaction bottleneck,
+ * the optional vision prefix / mapping network, the Lc-layer cross encoder, the
+ * pointwise (sigmoid/BCE), two-head (softmax/CE) or listwise (softmax/CE) scoring head
+ * and the descending stable top-K order, executed as hand-written HIP kernels on a
+ * caller-supplied HIP stream.
+ *
+ * Drop-in boundary (citations are into /root/reference/):
+ *   - the call `self.reranker(**batch_input)` in the Rerank executor
+ *     (src/executors/Reranker_base_executor.py:603,758,902-903,922) whose callee is
+ *     FullContextRerankModel.forward (src/models/rerank/rerank_model.py:523-591) /
+ *     RerankModel.forward (:171-331);
+ *   - the reference has no FFI of its own for this path (it is pure PyTorch), so the
+ *     entry points below are what a ctypes/pybind binding of that module's
+ *     __init__/load_state_dict/forward would bind.  INTEGRATION.md shows the
+ *     reference-side stub.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer marked DEVICE is a HIP device pointer
+ *     that the library BORROWS for the duration of the call; HOST pointers are read
+ *     before the call returns.
+ *   - every function returns rr_status (0 = ok, <0 = error); rr_last_error() gives a
+ *     human-readable message for the last failure on that handle.  The library never
+ *     aborts/exits and never silently falls back to a CPU path.
+ *   - a handle is NOT thread-safe; several handles per process are fine.  All kernels
+ *     are enqueued on the hipStream_t passed in (as void*); rr_forward does not
+ *     synchronise the device or the stream.
+ */
+#ifndef RERANK_MI355_H
+#define RERANK_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+typedef enum rr_status {
+  RR_OK = 0,
+  RR_ERR_BAD_ARG = -1,      /* null pointer / bad enum / handle misuse            (Python: ValueError)          */
+  RR_ERR_BAD_SHAPE = -2,    /* N != Bq*K, S > max_pos, label count ...            (Python: AssertionError,
+                                rerank_model.py:188-190,202,527-529)                                             */
+  RR_ERR_BAD_DTYPE = -3,    /* unsupported weight dtype                            (Python: ValueError,
+                                attention_fusion.py:97-100)                                                      */
+  RR_ERR_UNSUPPORTED = -4,  /* configuration the kernels do not cover              (Python: NotImplementedError,
+                                rerank_model.py:185, mores_model.py:72-73)                                       */
+  RR_ERR_HIP = -5,          /* a HIP runtime call failed                           (Python: RuntimeError)        */
+  RR_ERR_OOM = -6,          /* device allocation failed                            (Python: MemoryError)         */
+  RR_ERR_MISSING_WEIGHT = -7, /* rr_finalize_weights: a required tensor was never loaded (Python: KeyError)      */
+  RR_ERR_NO_DEVICE = -8     /* no gfx950 device visible                            (Python: RuntimeError)        */
+} rr_status;
+
+typedef enum rr_dtype { RR_F32 = 0, RR_BF16 = 1, RR_F16 = 2 } rr_dtype;
+
+/* scoring head / loss (src/models/rerank/utils.py:208-254) */
+typedef enum rr_loss_kind {
+  RR_LOSS_BCE = 0,               /* pointwise: BCEWithLogits(pos_weight), logits [N,1]                */
+  RR_LOSS_2H_BCE = 1,            /* two heads: CrossEntropy([l1,l2], weight=[1,pos_weight]); logits_out = l2 */
+  RR_LOSS_NEGATIVE_SAMPLING = 2  /* listwise: logits viewed [Bq,K], CrossEntropy(target = 0)          */
+} rr_loss_kind;
+
+/* Architecture.  Field names follow the reference configs
+ * (configuration_flmr.py:220-236,332-350; monoBERT_pointwise.jsonnet:111-122). */
+typedef struct rr_config {
+  int32_t abi_version;        /* = RR_ABI_VERSION */
+  /* FLMR text encoder (= BertModel) */
+  int32_t vocab_size, hidden, layers, heads, intermediate, max_pos, type_vocab;
+  float ln_eps;
+  int32_t li_dim;             /* late-interaction dim (128) */
+  /* cross encoder (rerank_model.py:89-101) */
+  int32_t ce_hidden, ce_layers, ce_heads, ce_intermediate, ce_max_pos;
+  /* vision prefix + transformer mapping network (modeling_flmr.py:603-664); has_vision=0 => text_only */
+  int32_t has_vision, vision_hidden, prefix_len, n_patches, map_layers, cross_attn_len;
+  /* head */
+  int32_t loss_kind;          /* rr_loss_kind */
+  float pos_weight;           /* NaN = none (utils.py:210,215) */
+  int32_t device;             /* HIP device ordinal */
+  int32_t reserved[7];
+} rr_config;
+
+typedef struct rr_model* rr_handle;
+
+/* Per-kernel-class device time accumulated while profiling is on (rr_set_profiling). */
+typedef enum rr_kernel_class {
+  RR_K_GEMM = 0, RR_K_ATTENTION = 1, RR_K_LAYERNORM = 2, RR_K_EMBED = 3, RR_K_TAIL = 4, RR_K_HEAD = 5,
+  RR_K_COUNT = 6
+} rr_kernel_class;
+
+typedef struct rr_profile {
+  double ms[RR_K_COUNT];      /* summed device ms per class (HIP events on the work stream) */
+  int64_t launches[RR_K_COUNT];
+  double flops[RR_K_COUNT];   /* algorithmic FLOPs issued per class (2*M*N*K, 4*T^2*dh per head ...) */
+  double bytes[RR_K_COUNT];   /* algorithmic HBM bytes (operands read once + results written once) */
+} rr_profile;
+
+const char* rr_version(void);
+const char* rr_status_string(int status);
+
+/* rr_create: allocate a model for `cfg` on cfg->device.  Replaces RerankerClass(reranker_config)
+ * (Reranker_base_executor.py:191-202 -> rerank_model.py:81-101,515-520). */
+int rr_create(const rr_config* cfg, rr_handle* out);
+int rr_destroy(rr_handle h);
+const char* rr_last_error(rr_handle h);
+
+/* rr_load_weight: copy ONE tensor (HOST pointer, row-major, `dtype`) into library-owned
+ * device memory, converting/packing as the kernels need.  `name` is the reference
+ * state_dict key without the executor's `reranker.` prefix, e.g.
+ * "context_text_encoder.bert_model.encoder.layer.0.attention.self.query.weight"
+ * (Reranker_base_executor.py:351-381 loads these with strict=False: unknown names are
+ * ignored and reported through *known = 0).  Replaces load_state_dict. */
+int rr_load_weight(rr_handle h, const char* name, const void* host_data, int dtype,
+                   int ndim, const int64_t* shape, int* known);
+/* rr_finalize_weights: verify every tensor the configured path reads was loaded, build
+ * fused/packed forms (QKV concat, 1/sqrt(dh) folded into Wq).  Must precede rr_forward. */
+int rr_finalize_weights(rr_handle h);
+/* number of tensors the configured path requires, and the i-th required name */
+int rr_num_required_weights(rr_handle h);
+const char* rr_required_weight_name(rr_handle h, int i);
+
+/* Bytes of grow-only device workspace rr_forward would hold for this shape. */
+int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len);
+
+/* rr_forward: one pass of the hot path over N = Bq*K (query,candidate) pairs.
+ *   input_ids, attention_mask, token_type_ids : DEVICE int64 [N,S] row-major, query-major pair order
+ *       (prepare_full_context_inputs, utils.py:129-167).  attention_mask masks keys in the text
+ *       encoder; the cross-encoder mask is (input_id != 0) (rerank_model.py:385-392,562).
+ *   image_cls     : DEVICE float32 [Bq, vision_hidden] or NULL (text_only) — CLIP last_hidden_state[:,0]
+ *   image_patches : DEVICE float32 [Bq, n_patches, vision_hidden] or NULL — CLIP hidden_states[-2][:,1:]
+ *       (per query; repeated over the K pairs inside, rerank_model.py:541-544)
+ *   labels        : DEVICE float32 [N] or NULL (NULL: first candidate of each query is the positive,
+ *       utils.py:239-243; must be NULL for RR_LOSS_NEGATIVE_SAMPLING, utils.py:233)
+ *   logits_out    : DEVICE float32 [N]   (= [N,1] pointwise / [Bq,K] listwise; 2H_BCE: second head)
+ *   logits2_out   : DEVICE float32 [N] or NULL (first head of 2H_BCE / classifier2 otherwise)
+ *   loss_out      : DEVICE float32 [1] or NULL
+ *   scores_out    : DEVICE float32 [N] or NULL — sigmoid(logit) (pointwise) / softmax over K (listwise)
+ *   order_out     : DEVICE int32 [Bq,K] or NULL — per query, candidate indices sorted by logit,
+ *       descending, ties in retrieval order (Reranker_base_executor.py:934-935)
+ *   pair_begin/pair_end : this rank's contiguous slice [pair_begin, pair_end) of the N pairs
+ *       (multi-GPU sharding; 0,N = everything).  Only that slice of logits_out is written; the head
+ *       (loss/scores/order) is computed by rr_head after the caller has all-gathered logits.
+ *       With the full range the head runs inside rr_forward.
+ */
+int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask,
+               const int64_t* token_type_ids, const float* image_cls, const float* image_patches,
+               int Bq, int K, int S, const float* labels, int pair_begin, int pair_end,
+               float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
+               int32_t* order_out, void* hip_stream);
+
+/* rr_head: scoring head + loss + top-K order over complete logits [Bq*K] (after the RCCL
+ * all-gather of per-rank slices).  Same semantics as the tail of rr_forward. */
+int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,
+            float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream);
+
+/* Debug taps: copy an internal activation of the LAST rr_forward to HOST memory as float32.
+ * names: "text_hidden" [n,S,H], "late_interaction" [n,T,D], "ce_hidden" [n,T,Hc]. Returns element
+ * count written, or <0.  Synchronises the stream.  Test-only. */
+int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems);
+
+int rr_set_debug(rr_handle h, int on);   /* keep a copy of the text-encoder output for rr_debug_read */
+
+/* Profiling: when on, rr_forward brackets every kernel launch with HIP events on the work
+ * stream; rr_get_profile synchronises, accumulates and returns the per-class totals. */
+int rr_set_profiling(rr_handle h, int on);
+int rr_get_profile(rr_handle h, rr_profile* out, int reset);
+
+/* Stand-alone operator entry points (unit parity tests call the kernels through these).
+ * All pointers DEVICE.  bf16 tensors are uint16_t bit patterns.  Kd % 64 == 0, N % 4 == 0. */
+int rr_op_gemm_bf16(const uint16_t* A /*[M,Kd]*/, const uint16_t* W /*[N,Kd]*/, const float* bias /*[N]|NULL*/,
+                    int M, int N, int Kd,
+                    int epilogue /*0: +bias -> bf16; 1: +bias, erf-GELU -> bf16; 2: +bias -> f32; 3: +bias, tanh -> bf16*/,
+                    void* out, void* hip_stream);
+/* out f32 [M,N] = A W^T + bias + resid */
+int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid /*[M,N]*/,
+                         int M, int N, int Kd, float* out, void* hip_stream);
+/* softmax(q k^T + key_bias) v per head (head dim 64; q is expected pre-scaled by 1/sqrt(64)).
+ * q row (b,t): q + ((b / q_batch_div) * Tq + t) * q_stride + head*64 ; k,v row (b,t): (b*Tk + t) * kv_stride + head*64;
+ * key_bias f32 [B,Tk] additive (0 = attend, -1e30 = masked) or NULL. */
+int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
+                         const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out,
+                         int out_stride, void* hip_stream);
+int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                    float* out_f32, uint16_t* out_bf16, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RERANK_MI355_H */

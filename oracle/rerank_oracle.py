@@ -1,0 +1,510 @@
+"""CPU oracle for the cross-encoder rerank forward.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, not the product: only `tests/`, `__graft_entry__.smoke()`
+and the `cpu_baseline` leg of `bench.py` may import it.  The product path
+(`rmr_amd`, `librerank_mi355.so`) never routes through it and has no CPU fallback.
+
+It restates, in plain fp32 `torch` tensor arithmetic on the CPU (no HuggingFace
+module, no autocast, no fused kernels), the algorithm of the reference's rerank
+hot path.  Every function cites the reference file:line (relative to
+`/root/reference/`) it follows.  The transformer-block arithmetic lives in a
+third-party dependency that is not vendored in the reference
+(`transformers==4.38.2`, `README.md:90-91`; classes `BertModel`, `BertEncoder`,
+`BertLayer`): its published algorithm (post-LN BERT, erf-GELU, eps 1e-12,
+softmax(QK^T/sqrt(dh) + additive mask) V) is restated here and anchored on the
+reference's own call sites.
+
+Parity pin: the reference has NO golden vectors / known-answer tests for this path
+("parity unpinned by the reference").  The restatement is pinned
+instead against the stock HuggingFace `BertModel`/`BertEncoder` (eager attention)
+assembled exactly as the reference assembles them; `tests/golden/make_golden.py`
+is the generator (runs only in the build container) and `tests/golden/*.npz` are
+the committed vectors.
+
+Weights are a flat dict {reference state_dict key (without the `reranker.` executor
+prefix) -> fp32 tensor}, e.g.
+  context_text_encoder.bert_model.encoder.layer.3.attention.self.query.weight
+  reranker.bert_model.embeddings.position_embeddings.weight
+  cross_encoder_input_mapping.weight
+(see SURVEY.md §5 "checkpoint / resume" for the naming).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+FMIN = torch.finfo(torch.float32).min
+
+
+# --------------------------------------------------------------------------- config
+@dataclass
+class OracleConfig:
+    """Architecture of the path.  Defaults = monoPreFLMR-B / bert-base-uncased
+    (`configuration_flmr.py:220-236,332`, `monoBERT_pointwise.jsonnet:111-122`)."""
+    vocab_size: int = 30522
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 3072
+    max_pos: int = 512
+    type_vocab: int = 2
+    ln_eps: float = 1e-12
+    li_dim: int = 128                      # late-interaction dim (configuration_flmr.py:332)
+    # cross encoder (rerank_model.py:89-101; bert-base-uncased shape, Lc layers, longer pos table)
+    ce_hidden: int = 768
+    ce_layers: int = 1
+    ce_heads: int = 12
+    ce_intermediate: int = 3072
+    ce_max_pos: int = 750
+    # vision side (modeling_flmr.py:603-664)
+    vision_hidden: int = 768
+    prefix_len: int = 32                   # mapping_network_prefix_length
+    n_patches: int = 49                    # ViT-B/32: 7x7 patches
+    map_layers: int = 1                    # transformer_mapping_num_hidden_layers
+    cross_attn_len: int = 32               # transformer_mapping_cross_attention_length
+    loss_fn: str = "BCE"                   # BCE | 2H_BCE | negative_sampling (utils.py:208-224)
+    pos_weight: Optional[float] = None
+
+
+# --------------------------------------------------------------------------- blocks
+def linear(x: Tensor, w: Dict[str, Tensor], name: str, mm=None) -> Tensor:
+    """y = x W^T + b (torch.nn.Linear).  `mm` lets tests swap in a bf16-rounding
+    matmul to emulate the device's rounding points; default = fp32."""
+    W = w[name + ".weight"]
+    b = w.get(name + ".bias")
+    y = (mm(x, W) if mm is not None else x @ W.t())
+    return y if b is None else y + b
+
+
+def layer_norm(x: Tensor, w: Dict[str, Tensor], name: str, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), w[name + ".weight"], w[name + ".bias"], eps)
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """HF `hidden_act="gelu"` = exact erf GELU (configuration_flmr.py:227)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def multi_head_attention(q: Tensor, k: Tensor, v: Tensor, heads: int,
+                         add_mask: Optional[Tensor]) -> Tensor:
+    """softmax(Q K^T / sqrt(dh) + mask) V  — HF 4.38 BertSelfAttention eager path
+    (transformers/models/bert/modeling_bert.py, called from modeling_flmr.py:1622 and
+    attention_fusion.py:133-144).  q:[B,Tq,H] k,v:[B,Tk,H]; add_mask broadcastable to
+    [B,heads,Tq,Tk] (additive, finfo.min on masked keys)."""
+    B, Tq, H = q.shape
+    Tk = k.shape[1]
+    dh = H // heads
+    qh = q.view(B, Tq, heads, dh).transpose(1, 2)
+    kh = k.view(B, Tk, heads, dh).transpose(1, 2)
+    vh = v.view(B, Tk, heads, dh).transpose(1, 2)
+    scores = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if add_mask is not None:
+        scores = scores + add_mask
+    probs = torch.softmax(scores, dim=-1)
+    ctx = probs @ vh
+    return ctx.transpose(1, 2).reshape(B, Tq, H)
+
+
+# ---- device rounding-point emulation (tests only) ------------------------------------------
+# The HIP path feeds bf16 operands to the MFMA (fp32 accumulate) and stores Q/K/V and the softmax
+# probabilities in bf16; everything else (residual stream, LayerNorm, softmax, GELU) is fp32.  These
+# two hooks reproduce exactly those rounding points on top of the fp32 restatement so that parity
+# tests can separate "bf16 operand rounding" (inherent, shared with the reference's bf16-mixed runs)
+# from kernel bugs.
+def _bf(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def mm_bf16(x: Tensor, W: Tensor) -> Tensor:
+    return _bf(x) @ _bf(W).t()
+
+
+def multi_head_attention_bf16(q: Tensor, k: Tensor, v: Tensor, heads: int, add_mask: Optional[Tensor]) -> Tensor:
+    B, Tq, H = q.shape
+    Tk = k.shape[1]
+    dh = H // heads
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    qh = q.view(B, Tq, heads, dh).transpose(1, 2)
+    kh = k.view(B, Tk, heads, dh).transpose(1, 2)
+    vh = v.view(B, Tk, heads, dh).transpose(1, 2)
+    scores = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if add_mask is not None:
+        scores = scores + add_mask
+    # device: P = exp2(s - max) is rounded to bf16 for the PV MFMA, the row sum stays fp32
+    m = scores.max(dim=-1, keepdim=True).values
+    e = torch.exp(scores - m)
+    ctx = (_bf(e) @ vh) / e.sum(dim=-1, keepdim=True)
+    return ctx.transpose(1, 2).reshape(B, Tq, H)
+
+
+_MHA = [multi_head_attention]
+
+
+class device_rounding:
+    """`with device_rounding() as mm:` — run the oracle with the device's bf16 rounding points."""
+
+    def __enter__(self):
+        _MHA.append(multi_head_attention_bf16)
+        return mm_bf16
+
+    def __exit__(self, *a):
+        _MHA.pop()
+        return False
+
+
+def extended_mask(mask01: Tensor) -> Tensor:
+    """`get_extended_attention_mask` / `invert_attention_mask` (utils.py:256-282,
+    attention_fusion.py:80-82): (1 - m) * finfo(fp32).min, shape [B,1,1,Tk]."""
+    return (1.0 - mask01.to(torch.float32))[:, None, None, :] * FMIN
+
+
+def bert_layer(h: Tensor, w: Dict[str, Tensor], p: str, heads: int, eps: float,
+               add_mask: Optional[Tensor], enc_h: Optional[Tensor] = None,
+               enc_mask: Optional[Tensor] = None, mm=None) -> Tensor:
+    """One post-LN BertLayer; with `enc_h` it is the decoder-configured layer of the
+    transformer mapping network: self-attn -> cross-attn -> FFN
+    (modeling_flmr.py:640-658, rerank_model.py:450-454)."""
+    q = linear(h, w, p + ".attention.self.query", mm)
+    k = linear(h, w, p + ".attention.self.key", mm)
+    v = linear(h, w, p + ".attention.self.value", mm)
+    ctx = _MHA[-1](q, k, v, heads, add_mask)
+    a = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + h, w,
+                   p + ".attention.output.LayerNorm", eps)
+    if enc_h is not None:
+        q = linear(a, w, p + ".crossattention.self.query", mm)
+        k = linear(enc_h, w, p + ".crossattention.self.key", mm)
+        v = linear(enc_h, w, p + ".crossattention.self.value", mm)
+        ctx = _MHA[-1](q, k, v, heads, enc_mask)
+        a = layer_norm(linear(ctx, w, p + ".crossattention.output.dense", mm) + a, w,
+                       p + ".crossattention.output.LayerNorm", eps)
+    inter = gelu_erf(linear(a, w, p + ".intermediate.dense", mm))
+    return layer_norm(linear(inter, w, p + ".output.dense", mm) + a, w, p + ".output.LayerNorm", eps)
+
+
+def bert_embeddings(w: Dict[str, Tensor], p: str, eps: float, input_ids: Optional[Tensor] = None,
+                    token_type_ids: Optional[Tensor] = None,
+                    inputs_embeds: Optional[Tensor] = None) -> Tensor:
+    """BertEmbeddings: (word | inputs_embeds) + token_type + position -> LayerNorm.
+    Absolute positions 0..T-1; token_type defaults to 0 (attention_fusion.py:66-76,126-132)."""
+    x = w[p + ".word_embeddings.weight"][input_ids] if inputs_embeds is None else inputs_embeds
+    B, T = x.shape[:2]
+    if token_type_ids is None:
+        token_type_ids = torch.zeros(B, T, dtype=torch.long)
+    x = x + w[p + ".token_type_embeddings.weight"][token_type_ids]
+    x = x + w[p + ".position_embeddings.weight"][:T][None]
+    return layer_norm(x, w, p + ".LayerNorm", eps)
+
+
+def text_encoder(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Tensor, attention_mask: Tensor,
+                 token_type_ids: Optional[Tensor], mm=None, taps: Optional[dict] = None) -> Tensor:
+    """FLMRTextModel.forward -> BertModel (modeling_flmr.py:1637-1688); returns
+    last_hidden_state [N,S,H]."""
+    p = "context_text_encoder.bert_model"
+    h = bert_embeddings(w, p + ".embeddings", cfg.ln_eps, input_ids, token_type_ids)
+    if taps is not None:
+        taps["text_emb"] = h
+    am = extended_mask(attention_mask)
+    for i in range(cfg.layers):
+        h = bert_layer(h, w, f"{p}.encoder.layer.{i}", cfg.heads, cfg.ln_eps, am, mm=mm)
+        if taps is not None:
+            taps[f"text_layer_{i}"] = h
+    return h
+
+
+def token_mask(input_ids: Tensor) -> Tensor:
+    """`RerankModel.mask` with empty skiplist (rerank_model.py:508-513): id != 0."""
+    return (input_ids != 0).to(torch.float32)
+
+
+def query_stage(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Tensor, attention_mask: Tensor,
+                token_type_ids: Optional[Tensor], image_cls: Optional[Tensor],
+                image_patches: Optional[Tensor], mm=None, taps: Optional[dict] = None
+                ) -> Tuple[Tensor, Tensor]:
+    """`RerankModel.query` (rerank_model.py:333-479) with `mask_instructions=False`.
+    The CLIP ViT itself is upstream of the path: `image_cls` is
+    `last_hidden_state[:,0]` [N,Vh] (rerank_model.py:411) and `image_patches` is
+    `hidden_states[-2][:,1:]` [N,np,Vh] (rerank_model.py:424-426), already repeated
+    per pair (rerank_model.py:541-544).
+    Returns (late_interaction_output [N,S(+P),D] L2-normalised, query_mask [N,S])."""
+    hs = text_encoder(cfg, w, input_ids, attention_mask, token_type_ids, mm, taps)
+    text = linear(hs, w, "context_text_encoder_linear", mm)             # :380-382 (no bias)
+    mask = token_mask(input_ids)                                         # :385-391
+    text = text * mask[..., None]                                        # :392
+    Q = text
+    if image_cls is not None:
+        N = image_cls.shape[0]
+        x = linear(image_cls, w, "context_vision_projection.model.0", mm)   # MLP modeling_flmr.py:531-546
+        x = linear(torch.tanh(x), w, "context_vision_projection.model.2", mm)
+        prefix = x.view(N, -1, cfg.li_dim)                                   # :419-421
+        t = linear(image_patches, w, "transformer_mapping_input_linear", mm)  # :428-430
+        enc = hs[:, : cfg.cross_attn_len]                                    # :438-442
+        enc_mask = extended_mask(torch.ones(N, enc.shape[1]))               # :433-447 (all ones)
+        for i in range(cfg.map_layers):
+            t = bert_layer(t, w, f"transformer_mapping_network.layer.{i}", cfg.heads, cfg.ln_eps,
+                           None, enc_h=enc, enc_mask=enc_mask, mm=mm)       # :450-454
+        t = linear(t, w, "transformer_mapping_output_linear", mm)           # :461-465
+        Q = torch.cat([text, prefix, t], dim=1)                              # :467-472
+        if taps is not None:
+            taps["vision_prefix"] = prefix
+            taps["vision_mapped"] = t
+    Q = F.normalize(Q, p=2, dim=2)                                           # :478 (eps 1e-12)
+    if taps is not None:
+        taps["late_interaction"] = Q
+    return Q, mask
+
+
+def cross_encoder(cfg: OracleConfig, w: Dict[str, Tensor], inputs_embeds: Tensor, mask01: Tensor,
+                  attention_adj: Optional[Tensor] = None, mm=None, taps: Optional[dict] = None
+                  ) -> Tuple[Tensor, Tensor]:
+    """`CrossEncoder.forward` (utils.py:85-108) over `AttentionFusionBertModel.forward`
+    (attention_fusion.py:61-160): embeddings(inputs_embeds) -> Lc layers -> CLS row ->
+    classifier1/2.  Pooler output is computed and discarded by the reference; skipped."""
+    p = "reranker.bert_model"
+    h = bert_embeddings(w, p + ".embeddings", cfg.ln_eps, inputs_embeds=inputs_embeds)
+    am = extended_mask(mask01)
+    if attention_adj is not None:                                           # attention_fusion.py:84-102
+        if attention_adj.dim() == 3:
+            attention_adj = attention_adj[:, None]
+        am = am + attention_adj
+    for i in range(cfg.ce_layers):
+        h = bert_layer(h, w, f"{p}.encoder.layer.{i}", cfg.ce_heads, cfg.ln_eps, am, mm=mm)
+        if taps is not None:
+            taps[f"ce_layer_{i}"] = h
+    cls = h[:, 0]                                                           # utils.py:102
+    return linear(cls, w, "reranker.classifier1"), linear(cls, w, "reranker.classifier2")
+
+
+# --------------------------------------------------------------------------- heads / loss
+def prepare_logits_labels(loss_fn: str, logits: Tensor, logits2: Tensor, Bq: int, num_neg: int,
+                          labels: Optional[Sequence[float]]):
+    """utils.py:228-254."""
+    lab = None
+    if labels is not None:
+        assert isinstance(labels, list), "Labels must be a list"
+        assert loss_fn != "negative_sampling", \
+            "Labels should not be provided for negative sampling loss function"
+        lab = torch.tensor(labels, dtype=torch.float32).reshape(-1, 1)
+    if loss_fn in ("BCE", "2H_BCE"):
+        if lab is None:
+            lab = torch.zeros(num_neg + 1, 1)
+            lab[0, 0] = 1
+            lab = lab.repeat(Bq, 1)
+        if loss_fn == "2H_BCE":
+            lab = lab.view(-1).long()
+            logits = torch.cat((logits, logits2), dim=1)
+    elif loss_fn == "negative_sampling":
+        logits = logits.view(-1, num_neg + 1)
+        lab = torch.zeros(Bq, dtype=torch.long)
+    else:
+        raise ValueError(f"Unknown loss function {loss_fn}")
+    return logits, lab
+
+
+def loss_value(loss_fn: str, pos_weight: Optional[float], logits: Tensor, labels: Tensor) -> Tensor:
+    """utils.py:208-224: BCEWithLogits(pos_weight) | CE(weight=[1,pos_weight]) | CE."""
+    if loss_fn == "BCE":
+        pw = torch.tensor([pos_weight]) if pos_weight is not None else None
+        return F.binary_cross_entropy_with_logits(logits, labels, pos_weight=pw)
+    if loss_fn == "2H_BCE":
+        cw = torch.tensor([1.0, pos_weight]) if pos_weight is not None else None
+        return F.cross_entropy(logits, labels, weight=cw)
+    if loss_fn == "negative_sampling":
+        return F.cross_entropy(logits, labels)
+    raise ValueError(f"Unknown loss function {loss_fn}")
+
+
+@dataclass
+class OracleOutput:
+    loss: Tensor
+    logits: Tensor
+    taps: dict = field(default_factory=dict)
+
+
+def full_context_forward(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Tensor,
+                         attention_mask: Tensor, token_type_ids: Tensor, Bq: int, K: int,
+                         image_cls: Optional[Tensor] = None, image_patches: Optional[Tensor] = None,
+                         labels: Optional[List[float]] = None, mm=None, want_taps: bool = False
+                         ) -> OracleOutput:
+    """`FullContextRerankModel.forward` (rerank_model.py:523-591) from the tokenised
+    pair batch onward (the tokenizer passes of utils.py:129-167 are upstream).
+    `image_cls` [Bq,Vh] / `image_patches` [Bq,np,Vh] are per *query* and repeated per
+    pair here exactly as `query_pixel_values.repeat_interleave(K)` does (:541-544)."""
+    N = Bq * K
+    assert N == input_ids.shape[0]                                          # :527
+    if labels:
+        assert len(labels) == N                                             # :528-529
+    taps = {} if want_taps else None
+    if image_cls is not None:
+        image_cls = image_cls.repeat_interleave(K, dim=0)
+        image_patches = image_patches.repeat_interleave(K, dim=0)
+    Q, qmask = query_stage(cfg, w, input_ids, attention_mask, token_type_ids, image_cls,
+                           image_patches, mm, taps)
+    x = linear(Q, w, "cross_encoder_input_mapping", mm)                     # :557-559
+    P = x.shape[1] - qmask.shape[1]
+    mask = torch.cat([qmask, torch.ones(N, P)], dim=1) if P > 0 else qmask  # :561-577
+    l1, l2 = cross_encoder(cfg, w, x, mask, None, mm, taps)                  # :580-583
+    logits, lab = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)  # :584
+    loss = loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)             # :587
+    if cfg.loss_fn == "2H_BCE":
+        logits = logits[:, 1].unsqueeze(1)                                  # :589-590
+    return OracleOutput(loss=loss, logits=logits, taps=taps or {})
+
+
+# --------------------------------------------------------------------------- rank + metric
+def rank_descending_stable(scores: Sequence[float]) -> List[int]:
+    """`sorted(zip(docs, logits), key=score, reverse=True)`
+    (Reranker_base_executor.py:934-935).  Python's sort is stable and `reverse=True`
+    preserves the original order of equal keys, so ties keep retrieval order."""
+    return [i for i, _ in sorted(enumerate(scores), key=lambda t: t[1], reverse=True)]
+
+
+def recall_precision_at_k(ranked_ids: Sequence[Sequence], pos_ids: Sequence[Sequence],
+                          Ks: Sequence[int]) -> Dict[str, List[float]]:
+    """`compute_rerank_DPR_scores_with_pos_ids` (metrics_processors.py:816-890):
+    recall@K = mean over queries of 1[any positive in top-K]; precision@K = mean of
+    hits-in-top-K / K."""
+    rec = [0.0] * len(Ks)
+    prec = [0.0] * len(Ks)
+    for ids, pos in zip(ranked_ids, pos_ids):
+        hit = [1 if pid in pos else 0 for pid in ids[: max(Ks)]]
+        for j, k in enumerate(Ks):
+            s = sum(hit[:k])
+            rec[j] += 1.0 if s > 0 else 0.0
+            prec[j] += s / k
+    n = max(1, len(ranked_ids))
+    return {"recall": [r / n for r in rec], "precision": [p / n for p in prec]}
+
+
+# --------------------------------------------------------------------------- synthetic data
+WEIGHT_SPEC_DOC = "see make_weights"
+
+
+def _layer_shapes(p: str, H: int, I: int, cross: bool) -> List[Tuple[str, Tuple[int, ...], str]]:
+    out = []
+    atts = ["attention"] + (["crossattention"] if cross else [])
+    for a in atts:
+        for n in ("query", "key", "value"):
+            out += [(f"{p}.{a}.self.{n}.weight", (H, H), "w"), (f"{p}.{a}.self.{n}.bias", (H,), "b")]
+        out += [(f"{p}.{a}.output.dense.weight", (H, H), "w"), (f"{p}.{a}.output.dense.bias", (H,), "b"),
+                (f"{p}.{a}.output.LayerNorm.weight", (H,), "g"), (f"{p}.{a}.output.LayerNorm.bias", (H,), "b")]
+    out += [(f"{p}.intermediate.dense.weight", (I, H), "w"), (f"{p}.intermediate.dense.bias", (I,), "b"),
+            (f"{p}.output.dense.weight", (H, I), "w"), (f"{p}.output.dense.bias", (H,), "b"),
+            (f"{p}.output.LayerNorm.weight", (H,), "g"), (f"{p}.output.LayerNorm.bias", (H,), "b")]
+    return out
+
+
+def weight_spec(cfg: OracleConfig, vision: bool) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Ordered (name, shape, kind) list of every tensor the path reads; kind in
+    {w: matrix, b: bias/beta, g: LN gamma, e: embedding}."""
+    H, I, D = cfg.hidden, cfg.intermediate, cfg.li_dim
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    p = "context_text_encoder.bert_model"
+    s += [(f"{p}.embeddings.word_embeddings.weight", (cfg.vocab_size, H), "e"),
+          (f"{p}.embeddings.position_embeddings.weight", (cfg.max_pos, H), "e"),
+          (f"{p}.embeddings.token_type_embeddings.weight", (cfg.type_vocab, H), "e"),
+          (f"{p}.embeddings.LayerNorm.weight", (H,), "g"), (f"{p}.embeddings.LayerNorm.bias", (H,), "b")]
+    for i in range(cfg.layers):
+        s += _layer_shapes(f"{p}.encoder.layer.{i}", H, I, False)
+    s += [("context_text_encoder_linear.weight", (D, H), "w")]
+    if vision:
+        Vh, PL = cfg.vision_hidden, cfg.prefix_len
+        s += [("context_vision_projection.model.0.weight", (D * PL // 2, Vh), "w"),
+              ("context_vision_projection.model.0.bias", (D * PL // 2,), "b"),
+              ("context_vision_projection.model.2.weight", (D * PL, D * PL // 2), "w"),
+              ("context_vision_projection.model.2.bias", (D * PL,), "b"),
+              ("transformer_mapping_input_linear.weight", (H, Vh), "w"),
+              ("transformer_mapping_input_linear.bias", (H,), "b")]
+        for i in range(cfg.map_layers):
+            s += _layer_shapes(f"transformer_mapping_network.layer.{i}", H, I, True)
+        s += [("transformer_mapping_output_linear.weight", (D, H), "w"),
+              ("transformer_mapping_output_linear.bias", (D,), "b")]
+    Hc, Ic = cfg.ce_hidden, cfg.ce_intermediate
+    s += [("cross_encoder_input_mapping.weight", (Hc, D), "w"), ("cross_encoder_input_mapping.bias", (Hc,), "b")]
+    p = "reranker.bert_model"
+    s += [(f"{p}.embeddings.position_embeddings.weight", (cfg.ce_max_pos, Hc), "e"),
+          (f"{p}.embeddings.token_type_embeddings.weight", (cfg.type_vocab, Hc), "e"),
+          (f"{p}.embeddings.LayerNorm.weight", (Hc,), "g"), (f"{p}.embeddings.LayerNorm.bias", (Hc,), "b")]
+    for i in range(cfg.ce_layers):
+        s += _layer_shapes(f"{p}.encoder.layer.{i}", Hc, Ic, False)
+    s += [("reranker.classifier1.weight", (1, Hc), "w"), ("reranker.classifier1.bias", (1,), "b"),
+          ("reranker.classifier2.weight", (1, Hc), "w"), ("reranker.classifier2.bias", (1,), "b")]
+    return s
+
+
+def make_weights(cfg: OracleConfig, seed: int = 0, vision: bool = False, hf_init: bool = False
+                 ) -> Dict[str, Tensor]:
+    """Seeded synthetic weights.  `hf_init=True`: HF init (matrices/embeddings
+    N(0,0.02), LN gamma 1 / beta 0, biases 0 — modeling_flmr.py:199-214) as the bench
+    uses; default (tests): same matrices but non-trivial biases/gamma/beta so that
+    every epilogue term is exercised.  Each tensor draws from its own generator
+    seeded by (seed, index) so the result does not depend on which tensors are present."""
+    w: Dict[str, Tensor] = {}
+    for idx, (name, shape, kind) in enumerate(weight_spec(cfg, vision)):
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        if kind in ("w", "e"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif kind == "g":
+            t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.zeros(shape) if hf_init else 0.05 * torch.randn(shape, generator=g)
+        w[name] = t
+    return w
+
+
+def make_pair_batch(cfg: OracleConfig, Bq: int, K: int, S: int, seed: int = 2022,
+                    regime: str = "realistic", q_len: int = 32):
+    """Synthetic tokenised pair batch per SURVEY §8d: [CLS] q.. [SEP] ctx.. [SEP] pad*;
+    body ids uniform in [1000, vocab); token_type 0 on `[CLS] q [SEP]`, 1 on `ctx [SEP]`,
+    0 on padding; `regime="full"`: all S positions real, `"realistic"`: total length
+    ~ U[min(64,S//2), S].  Returns int64 (ids, attention_mask, token_type_ids)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    N = Bq * K
+    ids = np.zeros((N, S), dtype=np.int64)
+    tt = np.zeros((N, S), dtype=np.int64)
+    lo = min(1000, cfg.vocab_size // 2)
+    ql = min(q_len, max(1, S // 4))
+    for n in range(N):
+        L = S if regime == "full" else int(rng.integers(min(64, S // 2), S + 1))
+        L = max(L, ql + 4)
+        body = rng.integers(lo, cfg.vocab_size, size=L)
+        body[0] = 101
+        body[ql + 1] = 102
+        body[L - 1] = 102
+        ids[n, :L] = body
+        tt[n, ql + 2: L] = 1
+    am = (ids != 0).astype(np.int64)
+    return torch.from_numpy(ids), torch.from_numpy(am), torch.from_numpy(tt)
+
+
+def make_image_feats(cfg: OracleConfig, Bq: int, seed: int = 2022):
+    g = torch.Generator().manual_seed(seed + 7)
+    cls = torch.randn(Bq, cfg.vision_hidden, generator=g)
+    patches = torch.randn(Bq, cfg.n_patches, cfg.vision_hidden, generator=g)
+    return cls, patches
+
+
+def flops_per_pair(cfg: OracleConfig, S: int, vision: bool) -> float:
+    """SURVEY §8d algorithmic FLOPs per pair: F_layer(T) = 8TH^2 + 4T^2H + 4THI;
+    F_pair = L F_layer(S) + 2SHD + 2(S+P)DHc + Lc F_layer_c(S+P) + F_vis."""
+    def fl(T, H, I):
+        return 8.0 * T * H * H + 4.0 * T * T * H + 4.0 * T * H * I
+    H, I, D = cfg.hidden, cfg.intermediate, cfg.li_dim
+    P = (cfg.prefix_len + cfg.n_patches) if vision else 0
+    f = cfg.layers * fl(S, H, I) + 2.0 * S * H * D + 2.0 * (S + P) * D * cfg.ce_hidden \
+        + cfg.ce_layers * fl(S + P, cfg.ce_hidden, cfg.ce_intermediate)
+    if vision:
+        Vh, npat, ca = cfg.vision_hidden, cfg.n_patches, cfg.cross_attn_len
+        mid = D * cfg.prefix_len // 2
+        f += 2.0 * (Vh * mid + mid * D * cfg.prefix_len)                       # MLP
+        f += 2.0 * npat * Vh * H + 2.0 * npat * H * D                            # in/out linears
+        per = (8.0 * npat * H * H + 4.0 * npat * npat * H                        # self-attn
+               + 4.0 * npat * H * H + 4.0 * ca * H * H + 4.0 * npat * ca * H     # cross-attn (q,o | k,v | scores)
+               + 4.0 * npat * H * I)
+        f += cfg.map_layers * per
+    return f

@@ -1,0 +1,209 @@
+// Fused multi-head attention (head dim 64) for gfx950:  O = softmax(Q K^T + key_bias) V
+//
+// Restates HF BertSelfAttention's eager path as the reference calls it
+// (/root/reference/src/models/flmr/models/flmr/modeling_flmr.py:1622 text encoder;
+//  src/models/rerank/attention_fusion.py:133-144 cross encoder; modeling_flmr.py:640-658 mapping
+//  network self/cross attention) without ever materialising the [N,heads,T,T] score tensor
+// (1.26 GB at c3).  1/sqrt(dh) is folded into Wq at weight-pack time
+// (0.125 is a power of two => bit-exact), so Q arrives pre-scaled.
+//
+// Structure: workgroup = 4 waves = 128 query rows of one (pair, head); wave = 32 query rows.
+//   * S^T = K Q^T is issued "swapped" (A-operand = K rows, B-operand = Q rows) with
+//     v_mfma_f32_32x32x16_bf16, so a lane owns ONE query column and 32 of the 64 keys of a tile:
+//     the softmax row reductions are in-register plus one lane<->lane+32 exchange, and the fp32
+//     accumulator tile is directly the B operand of the P·V product (cdna_hip_programming.md §3
+//     "An accumulator tile as the next MFMA's operand") — P never touches LDS;
+//   * O^T = V^T P^T: V is staged row-major [key][d] in LDS (coalesced from HBM) and consumed
+//     column-major through ds_read_b64_tr_b16 (hardware transpose, T10);
+//   * K/V tiles of 64 keys are double-buffered in LDS through registers (issue-early/write-late, T14):
+//     the next tile's global loads are in flight under this tile's 16 MFMAs;
+//   * key padding: additive fp32 bias per key in the log2 domain (0 valid, -1e30 masked, -inf beyond
+//     Tk).  finfo.min-style semantics are preserved: a row with no valid key attends uniformly to
+//     all Tk keys exactly like softmax over a constant row does in the reference.
+#include "rr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KT = 64;                     // keys per tile
+constexpr int TILE_BYTES = KT * 64 * 2;    // 8 KiB (K or V tile)
+
+// V image: 128-byte rows, 16-byte chunk index XORed with 4*((row>>1)&1): the 4 rows x 64 bytes a
+// half-wave touches in one ds_read_b64_tr_b16 then cover all 64 banks once.
+__device__ __forceinline__ int vswz(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_off, int lane) {
+  // two transposed 4x16 blocks: keys key0..key0+3 and key0+8..key0+11, columns by lane group.
+  const int i = lane & 15, qd = i >> 2, p = i & 3;
+  const int c = d_chunk_off + (p >> 1);
+  const int o = (p & 1) * 8;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(vt + vswz(key0 + qd, c) + o));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(vt + vswz(key0 + 8 + qd, c) + o));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
+                                                       int q_batch_div, int q_batch_off,
+                                                       const bf16_t* __restrict__ k,
+                                                       const bf16_t* __restrict__ v, int kv_stride,
+                                                       const float* __restrict__ key_bias, int heads,
+                                                       int Tq, int Tk, bf16_t* __restrict__ out,
+                                                       int out_stride) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4];
+  char* const k_img = lds;                       // [2][8 KiB]
+  char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
+  float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64]
+
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+
+  // ---- Q fragments (B operand of S^T = K Q^T): Q[query = lane&31][d = 16 i + 8 h + j]
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = q + ((size_t)((b + q_batch_off) / q_batch_div) * Tq + min(qrow, Tq - 1)) * q_stride + head * 64 + 8 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qf[i] = *(const bf16x8*)(qp + 16 * i);
+  }
+
+  // ---- K/V tile staging through registers: thread handles 16-byte chunks idx = tid, tid + 256
+  const bf16_t* kbase = k + (size_t)b * Tk * kv_stride + head * 64;
+  const bf16_t* vbase = v + (size_t)b * Tk * kv_stride + head * 64;
+  uint4 kr0, kr1, vr0, vr1;
+  float br = 0.f;
+  const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;   // chunk idx = tid, tid + 256
+#define RR_LOAD_TILE(t)                                                                         \
+  {                                                                                             \
+    const size_t off0 = (size_t)min((t) * KT + srow0, Tk - 1) * kv_stride + sc * 8;             \
+    const size_t off1 = (size_t)min((t) * KT + srow1, Tk - 1) * kv_stride + sc * 8;             \
+    kr0 = *(const uint4*)(kbase + off0); kr1 = *(const uint4*)(kbase + off1);                   \
+    vr0 = *(const uint4*)(vbase + off0); vr1 = *(const uint4*)(vbase + off1);                   \
+    if (tid < KT) {                                                                             \
+      const int key = (t) * KT + tid;                                                           \
+      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] * LOG2E : 0.f) : -INFINITY;    \
+    }                                                                                           \
+  }
+#define RR_WRITE_TILE(buf)                                                                      \
+  {                                                                                             \
+    *(uint4*)(k_img + (buf) * TILE_BYTES + swz128(srow0, sc)) = kr0;                            \
+    *(uint4*)(k_img + (buf) * TILE_BYTES + swz128(srow1, sc)) = kr1;                            \
+    *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow0, sc)) = vr0;                              \
+    *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow1, sc)) = vr1;                              \
+    if (tid < KT) b_img[(buf) * KT + tid] = br;                                                 \
+  }
+
+  f32x16 o0, o1;   // O^T[d = 32*dblk + (r&3) + 8(r>>2) + 4h][query = lane&31]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;   // running max (log2 domain) and this lane's partial row sum
+
+  const int nt = (Tk + KT - 1) / KT;
+  RR_LOAD_TILE(0)
+  RR_WRITE_TILE(0)
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) RR_LOAD_TILE(t + 1)
+    const char* kt_ = k_img + buf * TILE_BYTES;
+    const char* vt_ = v_img + buf * TILE_BYTES;
+    const float* bt_ = b_img + buf * KT;
+
+    // ---- S^T tile: keys 0..31 -> s0, 32..63 -> s1; reg r <-> key (r&3) + 8(r>>2) + 4h
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 k0 = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
+      const bf16x8 k1 = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[i], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[i], s1, 0, 0, 0);
+    }
+    // ---- log2-domain scores + key bias, tile row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
+      const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
+      s0[4 * g + 0] = fmaf(s0[4 * g + 0], LOG2E, b0.x); s0[4 * g + 1] = fmaf(s0[4 * g + 1], LOG2E, b0.y);
+      s0[4 * g + 2] = fmaf(s0[4 * g + 2], LOG2E, b0.z); s0[4 * g + 3] = fmaf(s0[4 * g + 3], LOG2E, b0.w);
+      s1[4 * g + 0] = fmaf(s1[4 * g + 0], LOG2E, b1.x); s1[4 * g + 1] = fmaf(s1[4 * g + 1], LOG2E, b1.y);
+      s1[4 * g + 2] = fmaf(s1[4 * g + 2], LOG2E, b1.z); s1[4 * g + 3] = fmaf(s1[4 * g + 3], LOG2E, b1.w);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 in-range key
+    const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = exp2f(s0[r] - m_new);
+      s1[r] = exp2f(s1[r] - m_new);
+      ps += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+    // ---- O^T += V^T P^T.  P fragment for k-step s of key block kb = regs 8s..8s+7 (k order:
+    // element j <-> key 16 s + 8 (j>>2) + 4 h + (j&3)); V fragment gathers the same keys.
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        u32x4 pw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = kb == 0 ? s0[8 * s + 2 * j] : s1[8 * s + 2 * j];
+          const float hi = kb == 0 ? s0[8 * s + 2 * j + 1] : s1[8 * s + 2 * j + 1];
+          pw[j] = pack2bf(lo, hi);
+        }
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        const int key0 = kb * 32 + 16 * s + 4 * h;
+        const int cg = 2 * ((lane >> 4) & 1);      // 16-lane group -> d columns 16*(g&1) within the 32-d block
+        const bf16x8 v0 = tr_pair(vt_, key0, 0 + cg, lane);   // d block 0: chunks 0..3
+        const bf16x8 v1 = tr_pair(vt_, key0, 4 + cg, lane);   // d block 1: chunks 4..7
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = O^T / l ; lane writes 4 consecutive d per register group
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < Tq) {
+    bf16_t* op = out + ((size_t)b * Tq + qrow) * out_stride + head * 64 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(uint2*)(op + 8 * g) = make_uint2(pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                         pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                              pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
+                               const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
+                               int Tq, int Tk, bf16_t* out, int out_stride, hipStream_t st) {
+  if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
+  if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
+  if (B > 65535 || heads > 65535) return hipErrorInvalidValue;
+  dim3 grid((Tq + 127) / 128, heads, B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
+                     key_bias, heads, Tq, Tk, out, out_stride);
+  return hipGetLastError();
+}

@@ -1,0 +1,296 @@
+// HBM-bound row kernels of the rerank path (gfx950): embeddings + LayerNorm, LayerNorm, the
+// late-interaction bottleneck's mask / L2-normalise / concat, cross-encoder input embeddings,
+// key-padding bias, small gathers/casts, CLS classifier heads.  One wave (64 lanes) owns one row,
+// 16-byte vector loads/stores, wave-shuffle reductions; fp32 statistics throughout.
+//
+// Reference anchors (/root/reference/): BertEmbeddings + LayerNorm as called through
+// modeling_flmr.py:1622 and attention_fusion.py:126-132; mask / normalise rerank_model.py:385-392,
+// 471-478; classifier heads utils.py:101-108.
+#include "rr_common.h"
+
+namespace {
+
+constexpr int MAX_V4 = 8;   // row length <= 64 lanes * 8 float4 = 2048 columns
+
+struct RowStats { float mean, rstd; };
+
+// v[i] holds float4 index lane + 64 i of the row (zeros beyond n4).
+__device__ __forceinline__ RowStats row_stats(const float4 (&v)[MAX_V4], int n4, int lane, int cols, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i)
+    if (lane + 64 * i < n4) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i)
+    if (lane + 64 * i < n4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  const float var = wave_sum(q) / (float)cols;
+  return RowStats{mean, 1.0f / sqrtf(var + eps)};
+}
+
+__device__ __forceinline__ void ln_store(const float4 (&v)[MAX_V4], RowStats st, const float* gamma,
+                                         const float* beta, int n4, int lane, float* o32, bf16_t* o16) {
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float4 g = ((const float4*)gamma)[c4], b = ((const float4*)beta)[c4];
+      float4 y;
+      y.x = (v[i].x - st.mean) * st.rstd * g.x + b.x;
+      y.y = (v[i].y - st.mean) * st.rstd * g.y + b.y;
+      y.z = (v[i].z - st.mean) * st.rstd * g.z + b.z;
+      y.w = (v[i].w - st.mean) * st.rstd * g.w + b.w;
+      if (o32) ((float4*)o32)[c4] = y;
+      if (o16) ((uint2*)o16)[c4] = make_uint2(pack2bf(y.x, y.y), pack2bf(y.z, y.w));
+    }
+  }
+}
+
+// ---- LayerNorm over fp32 rows -> fp32 (residual stream) + bf16 (next GEMM operand)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int rows,
+                                                        int cols, float* __restrict__ o32, bf16_t* __restrict__ o16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2;
+  float4 v[MAX_V4];
+  const float4* xr = (const float4*)(x + (size_t)row * cols);
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) v[i] = (lane + 64 * i < n4) ? xr[lane + 64 * i] : make_float4(0, 0, 0, 0);
+  const RowStats st = row_stats(v, n4, lane, cols, eps);
+  ln_store(v, st, gamma, beta, n4, lane, o32 ? o32 + (size_t)row * cols : nullptr,
+           o16 ? o16 + (size_t)row * cols : nullptr);
+}
+
+// ---- BertEmbeddings from ids: word[id] + type[tt] + pos[s] -> LN
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
+                                                       const float* __restrict__ word, const float* __restrict__ pos,
+                                                       const float* __restrict__ type, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int rows, int S,
+                                                       int cols, int vocab, int type_vocab,
+                                                       float* __restrict__ o32, bf16_t* __restrict__ o16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2;
+  int64_t id = ids[row], tt = tts ? tts[row] : 0;
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);           // host validates; clamp keeps loads in bounds
+  tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+  const float4* wr = (const float4*)(word + (size_t)id * cols);
+  const float4* tr = (const float4*)(type + (size_t)tt * cols);
+  const float4* pr = (const float4*)(pos + (size_t)(row % S) * cols);
+  float4 v[MAX_V4];
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float4 a = wr[c4], b = tr[c4], c = pr[c4];
+      // same association as HF: (inputs_embeds + token_type_embeddings) + position_embeddings
+      v[i] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+    } else {
+      v[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  const RowStats st = row_stats(v, n4, lane, cols, eps);
+  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols);
+}
+
+// ---- cross-encoder embeddings from inputs_embeds: x + type[0] + pos[t] -> LN  (row = pair*T + t)
+__global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                          const float* __restrict__ type0,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int rows, int T,
+                                                          int cols, float* __restrict__ o32, bf16_t* __restrict__ o16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2;
+  const float4* xr = (const float4*)(x + (size_t)row * cols);
+  const float4* pr = (const float4*)(pos + (size_t)(row % T) * cols);
+  const float4* tr = (const float4*)type0;
+  float4 v[MAX_V4];
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float4 a = xr[c4], b = tr[c4], c = pr[c4];
+      v[i] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+    } else {
+      v[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  const RowStats st = row_stats(v, n4, lane, cols, eps);
+  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols);
+}
+
+// ---- late-interaction rows: (x * mask) -> L2 normalise (F.normalize eps 1e-12) -> bf16, scattered
+// into the concatenated [pairs, T, D] buffer.  src row r = sb * rows_per_batch + j; it is written to
+// every destination pair p with (p + pair_off) / bdiv == sb + src_batch_off... expressed from the
+// destination side: one wave per destination row.
+__global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids,
+                                                           int ids_stride, int n_pairs, int rows_per_batch, int D,
+                                                           int T, int t_off, int pair_off, int bdiv,
+                                                           int src_batch_off, bf16_t* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_pairs * rows_per_batch) return;
+  const int p = r / rows_per_batch, j = r - p * rows_per_batch;
+  const int sb = (p + pair_off) / bdiv - src_batch_off;
+  const float* s = src + ((size_t)sb * rows_per_batch + j) * D;
+  const float m = ids ? (ids[(size_t)p * ids_stride + j] != 0 ? 1.0f : 0.0f) : 1.0f;
+  const int n4 = D >> 2;
+  float4 v[MAX_V4];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      float4 a = ((const float4*)s)[c4];
+      a.x *= m; a.y *= m; a.z *= m; a.w *= m;
+      v[i] = a;
+      q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+  }
+  const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+  bf16_t* d = dst + ((size_t)p * T + t_off + j) * D;
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4)
+      ((uint2*)d)[c4] = make_uint2(pack2bf(v[i].x / nrm, v[i].y / nrm), pack2bf(v[i].z / nrm, v[i].w / nrm));
+  }
+}
+
+// ---- key-padding bias rows: text encoder from attention_mask, cross encoder from (id != 0) + ones
+__global__ void key_bias_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ am, int n, int S, int T,
+                                float* __restrict__ text_bias, float* __restrict__ ce_bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * T) return;
+  const int p = i / T, t = i - p * T;
+  if (t < S) {
+    text_bias[(size_t)p * S + t] = am[(size_t)p * S + t] != 0 ? 0.f : -1e30f;
+    ce_bias[i] = ids[(size_t)p * S + t] != 0 ? 0.f : -1e30f;
+  } else {
+    ce_bias[i] = 0.f;
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = ((const float4*)x)[i];
+  ((uint2*)y)[i] = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+}
+
+// rows (dst_batch, j<rows_take) <- src row (dst_batch + off)/bdiv - src_off : generic 16-byte row gather/broadcast
+__global__ void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int n_dst_batches,
+                                   int rows_take, int src_rows_per_batch, int row_u4, int batch_off, int bdiv,
+                                   int src_batch_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_dst_batches * rows_take * row_u4;
+  if (i >= total) return;
+  const int c = (int)(i % row_u4);
+  const size_t rj = i / row_u4;
+  const int j = (int)(rj % rows_take), p = (int)(rj / rows_take);
+  const int sb = (p + batch_off) / bdiv - src_batch_off;
+  dst[i] = src[((size_t)sb * src_rows_per_batch + j) * row_u4 + c];
+}
+
+// ---- CLS classifier heads: logit_k[p] = <h32[p*T + 0, :], w_k> + b_k   (utils.py:101-108)
+__global__ __launch_bounds__(256) void cls_heads_kernel(const float* __restrict__ h32, int T, int cols, int n_pairs,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ out1, float* __restrict__ out2) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_pairs) return;
+  const float4* x = (const float4*)(h32 + (size_t)p * T * cols);
+  float a1 = 0.f, a2 = 0.f;
+  for (int c4 = lane; c4 < (cols >> 2); c4 += 64) {
+    const float4 v = x[c4], u1 = ((const float4*)w1)[c4], u2 = ((const float4*)w2)[c4];
+    a1 += (v.x * u1.x + v.y * u1.y) + (v.z * u1.z + v.w * u1.w);
+    a2 += (v.x * u2.x + v.y * u2.y) + (v.z * u2.z + v.w * u2.w);
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) {
+    out1[p] = a1 + b1[0];
+    if (out2) out2[p] = a2 + b2[0];
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                               float* out_f32, bf16_t* out_bf16, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
+                     out_f32, out_bf16);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_embed_ln(const int64_t* ids, const int64_t* tts, const float* word, const float* pos,
+                              const float* type, const float* gamma, const float* beta, float eps, int rows, int S,
+                              int cols, int vocab, int type_vocab, float* o32, bf16_t* o16, hipStream_t st) {
+  if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ids, tts, word, pos, type, gamma,
+                     beta, eps, rows, S, cols, vocab, type_vocab, o32, o16);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* type0, const float* gamma,
+                                 const float* beta, float eps, int rows, int T, int cols, float* o32, bf16_t* o16,
+                                 hipStream_t st) {
+  if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ce_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, pos, type0, gamma, beta, eps,
+                     rows, T, cols, o32, o16);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_li_normalize(const float* src, const int64_t* ids, int ids_stride, int n_pairs,
+                                  int rows_per_batch, int D, int T, int t_off, int pair_off, int bdiv,
+                                  int src_batch_off, bf16_t* dst, hipStream_t st) {
+  if (n_pairs <= 0 || rows_per_batch <= 0 || (D & 3) || D > 64 * 4 * MAX_V4 || bdiv <= 0) return hipErrorInvalidValue;
+  const int rows = n_pairs * rows_per_batch;
+  hipLaunchKernelGGL(li_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, src, ids, ids_stride, n_pairs,
+                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_key_bias(const int64_t* ids, const int64_t* am, int n, int S, int T, float* text_bias,
+                              float* ce_bias, hipStream_t st) {
+  const int total = n * T;
+  hipLaunchKernelGGL(key_bias_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ids, am, n, S, T, text_bias,
+                     ce_bias);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_f32_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
+  if (n & 3) return hipErrorInvalidValue;
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, n4);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_gather_rows(const void* src, void* dst, int n_dst_batches, int rows_take, int src_rows_per_batch,
+                                 int row_bytes, int batch_off, int bdiv, int src_batch_off, hipStream_t st) {
+  if (row_bytes & 15) return hipErrorInvalidValue;
+  const size_t total = (size_t)n_dst_batches * rows_take * (row_bytes >> 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4*)src,
+                     (uint4*)dst, n_dst_batches, rows_take, src_rows_per_batch, row_bytes >> 4, batch_off, bdiv,
+                     src_batch_off);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_cls_heads(const float* h32, int T, int cols, int n_pairs, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* out1, float* out2, hipStream_t st) {
+  hipLaunchKernelGGL(cls_heads_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, st, h32, T, cols, n_pairs, w1, b1, w2,
+                     b2, out1, out2);
+  return hipGetLastError();
+}

@@ -1,0 +1,856 @@
+// librerank_mi355 — C ABI implementation (see include/rerank_mi355.h for the contract).
+//
+// Host-side orchestration of the rerank forward as a fixed kernel sequence on one HIP stream.
+// The sequence restates /root/reference/src/models/rerank/rerank_model.py:523-591
+// (FullContextRerankModel.forward) -> :333-479 (RerankModel.query) -> utils.py:85-108 (CrossEncoder)
+// -> utils.py:228-254 (head); everything runs on the device, there is no CPU fallback.
+#include "../../include/rerank_mi355.h"
+#include "rr_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// launchers implemented in the other translation units
+hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*,
+                              const float*, float, int, int, int, int, int, float*, bf16_t*, hipStream_t);
+hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
+                                 int, float*, bf16_t*, hipStream_t);
+hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
+                                  hipStream_t);
+hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
+hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, hipStream_t);
+hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+hipError_t rr_launch_cls_heads(const float*, int, int, int, const float*, const float*, const float*, const float*,
+                               float*, float*, hipStream_t);
+hipError_t rr_launch_head(const float*, const float*, const float*, int, int, int, float, int, float*, int32_t*,
+                          float*, float*, float*, hipStream_t);
+
+namespace {
+
+uint16_t host_f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float host_bf2f(uint16_t b) {
+  uint32_t u = ((uint32_t)b) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+float host_h2f(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+  float v;
+  if (e == 0) v = ldexpf((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = ldexpf((float)(m | 1024), (int)e - 25);
+  return s ? -v : v;
+}
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+// Per-BertLayer device weights (fused/packed forms).
+struct LayerW {
+  bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  // cross-attention (transformer mapping network only)
+  bf16_t *wq_c = nullptr, *wkv_c = nullptr, *wo_c = nullptr;
+  float *bq_c = nullptr, *bkv_c = nullptr, *bo_c = nullptr, *lncg = nullptr, *lncb = nullptr;
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int kclass;
+};
+
+}  // namespace
+
+struct rr_model {
+  rr_config cfg;
+  std::string err;
+  bool finalized = false;
+  std::map<std::string, std::vector<int64_t>> required;   // name -> expected shape
+  std::vector<std::string> required_order;
+  std::map<std::string, HostTensor> host;                  // staged until finalize
+  std::vector<void*> dev_allocs;
+
+  // device weights
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+  std::vector<LayerW> text_layers, ce_layers, map_layers;
+  bf16_t* w_li = nullptr;                                   // context_text_encoder_linear [D,H]
+  bf16_t *w_vp0 = nullptr, *w_vp2 = nullptr, *w_min = nullptr, *w_mout = nullptr;
+  float *b_vp0 = nullptr, *b_vp2 = nullptr, *b_min = nullptr, *b_mout = nullptr;
+  bf16_t* w_cemap = nullptr;
+  float* b_cemap = nullptr;
+  float *ce_pos = nullptr, *ce_type = nullptr, *ce_emb_g = nullptr, *ce_emb_b = nullptr;
+  float *cls1_w = nullptr, *cls1_b = nullptr, *cls2_w = nullptr, *cls2_b = nullptr;
+
+  // workspace (grow-only)
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+
+  // last-forward taps
+  bool debug = false;
+  float* tap_text = nullptr;
+  size_t tap_text_elems = 0;
+  const bf16_t* tap_li = nullptr;
+  size_t tap_li_elems = 0;
+  const float* tap_ce = nullptr;
+  size_t tap_ce_elems = 0;
+  hipStream_t last_stream = nullptr;
+
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEvent> ev_pool;
+  size_t ev_used = 0;
+  rr_profile prof{};
+};
+
+namespace {
+
+int fail(rr_model* m, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf;
+  return code;
+}
+
+#define RR_HIP(m, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(m, e_ == hipErrorOutOfMemory ? RR_ERR_OOM : RR_ERR_HIP, "%s failed: %s", #call, \
+                  hipGetErrorString(e_));                                                      \
+  } while (0)
+
+struct Prof {
+  rr_model* m;
+  hipStream_t st;
+  int idx = -1;
+  Prof(rr_model* m_, hipStream_t st_, int kclass, double flops, double bytes) : m(m_), st(st_) {
+    if (!m->profiling) return;
+    if (m->ev_used == m->ev_pool.size()) {
+      ProfEvent e{};
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      m->ev_pool.push_back(e);
+    }
+    idx = (int)m->ev_used++;
+    m->ev_pool[idx].kclass = kclass;
+    m->prof.launches[kclass] += 1;
+    m->prof.flops[kclass] += flops;
+    m->prof.bytes[kclass] += bytes;
+    (void)hipEventRecord(m->ev_pool[idx].a, st);
+  }
+  ~Prof() {
+    if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].b, st);
+  }
+};
+
+#define RR_RUN(m, st, kclass, flops, bytes, call)                                              \
+  do {                                                                                         \
+    hipError_t e_;                                                                             \
+    {                                                                                          \
+      Prof p_(m, st, kclass, flops, bytes);                                                    \
+      e_ = (call);                                                                             \
+    }                                                                                          \
+    if (e_ != hipSuccess) return fail(m, RR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- required-weight table -------------------------------------------------------------------
+void req(rr_model* m, const std::string& name, std::vector<int64_t> shape) {
+  m->required[name] = std::move(shape);
+  m->required_order.push_back(name);
+}
+void req_layer(rr_model* m, const std::string& p, int H, int I, bool cross) {
+  const char* atts[2] = {"attention", "crossattention"};
+  for (int a = 0; a < (cross ? 2 : 1); ++a) {
+    const std::string ap = p + "." + atts[a];
+    for (const char* n : {"query", "key", "value"}) {
+      req(m, ap + ".self." + n + ".weight", {H, H});
+      req(m, ap + ".self." + n + ".bias", {H});
+    }
+    req(m, ap + ".output.dense.weight", {H, H});
+    req(m, ap + ".output.dense.bias", {H});
+    req(m, ap + ".output.LayerNorm.weight", {H});
+    req(m, ap + ".output.LayerNorm.bias", {H});
+  }
+  req(m, p + ".intermediate.dense.weight", {I, H});
+  req(m, p + ".intermediate.dense.bias", {I});
+  req(m, p + ".output.dense.weight", {H, I});
+  req(m, p + ".output.dense.bias", {H});
+  req(m, p + ".output.LayerNorm.weight", {H});
+  req(m, p + ".output.LayerNorm.bias", {H});
+}
+void build_required(rr_model* m) {
+  const rr_config& c = m->cfg;
+  const int H = c.hidden, I = c.intermediate, D = c.li_dim;
+  std::string p = "context_text_encoder.bert_model";
+  req(m, p + ".embeddings.word_embeddings.weight", {c.vocab_size, H});
+  req(m, p + ".embeddings.position_embeddings.weight", {c.max_pos, H});
+  req(m, p + ".embeddings.token_type_embeddings.weight", {c.type_vocab, H});
+  req(m, p + ".embeddings.LayerNorm.weight", {H});
+  req(m, p + ".embeddings.LayerNorm.bias", {H});
+  for (int i = 0; i < c.layers; ++i) req_layer(m, p + ".encoder.layer." + std::to_string(i), H, I, false);
+  req(m, "context_text_encoder_linear.weight", {D, H});
+  if (c.has_vision) {
+    const int Vh = c.vision_hidden, mid = D * c.prefix_len / 2, outd = D * c.prefix_len;
+    req(m, "context_vision_projection.model.0.weight", {mid, Vh});
+    req(m, "context_vision_projection.model.0.bias", {mid});
+    req(m, "context_vision_projection.model.2.weight", {outd, mid});
+    req(m, "context_vision_projection.model.2.bias", {outd});
+    req(m, "transformer_mapping_input_linear.weight", {H, Vh});
+    req(m, "transformer_mapping_input_linear.bias", {H});
+    for (int i = 0; i < c.map_layers; ++i)
+      req_layer(m, "transformer_mapping_network.layer." + std::to_string(i), H, I, true);
+    req(m, "transformer_mapping_output_linear.weight", {D, H});
+    req(m, "transformer_mapping_output_linear.bias", {D});
+  }
+  const int Hc = c.ce_hidden, Ic = c.ce_intermediate;
+  req(m, "cross_encoder_input_mapping.weight", {Hc, D});
+  req(m, "cross_encoder_input_mapping.bias", {Hc});
+  p = "reranker.bert_model";
+  req(m, p + ".embeddings.position_embeddings.weight", {c.ce_max_pos, Hc});
+  req(m, p + ".embeddings.token_type_embeddings.weight", {c.type_vocab, Hc});
+  req(m, p + ".embeddings.LayerNorm.weight", {Hc});
+  req(m, p + ".embeddings.LayerNorm.bias", {Hc});
+  for (int i = 0; i < c.ce_layers; ++i) req_layer(m, p + ".encoder.layer." + std::to_string(i), Hc, Ic, false);
+  req(m, "reranker.classifier1.weight", {1, Hc});
+  req(m, "reranker.classifier1.bias", {1});
+  req(m, "reranker.classifier2.weight", {1, Hc});
+  req(m, "reranker.classifier2.bias", {1});
+}
+
+// ---- device upload helpers -------------------------------------------------------------------
+int dev_alloc(rr_model* m, void** out, size_t bytes) {
+  RR_HIP(m, hipMalloc(out, bytes ? bytes : 16));
+  m->dev_allocs.push_back(*out);
+  return RR_OK;
+}
+int up_f32(rr_model* m, const std::vector<float>& v, float** out) {
+  int rc = dev_alloc(m, (void**)out, v.size() * 4);
+  if (rc) return rc;
+  RR_HIP(m, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return RR_OK;
+}
+int up_bf16(rr_model* m, const std::vector<float>& v, bf16_t** out) {
+  std::vector<uint16_t> t(v.size());
+  for (size_t i = 0; i < v.size(); ++i) t[i] = host_f2bf(v[i]);
+  int rc = dev_alloc(m, (void**)out, t.size() * 2);
+  if (rc) return rc;
+  RR_HIP(m, hipMemcpy(*out, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+  return RR_OK;
+}
+const std::vector<float>& HT(rr_model* m, const std::string& n) { return m->host.at(n).data; }
+
+std::vector<float> cat(std::initializer_list<const std::vector<float>*> parts, float first_scale) {
+  std::vector<float> o;
+  bool first = true;
+  for (auto* p : parts) {
+    const size_t n0 = o.size();
+    o.insert(o.end(), p->begin(), p->end());
+    if (first && first_scale != 1.0f)
+      for (size_t i = n0; i < o.size(); ++i) o[i] *= first_scale;
+    first = false;
+  }
+  return o;
+}
+
+#define RR_TRY(x)            \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != RR_OK) return rc_; \
+  } while (0)
+
+int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross, LayerW* L) {
+  const float qs = 1.0f / sqrtf((float)(Hd / heads));   // 1/sqrt(dh): 0.125 for dh = 64 (exact in bf16)
+  const std::string a = p + ".attention";
+  RR_TRY(up_bf16(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs), &L->wqkv));
+  RR_TRY(up_f32(m, cat({&HT(m, a + ".self.query.bias"), &HT(m, a + ".self.key.bias"), &HT(m, a + ".self.value.bias")}, qs), &L->bqkv));
+  RR_TRY(up_bf16(m, HT(m, a + ".output.dense.weight"), &L->wo));
+  RR_TRY(up_f32(m, HT(m, a + ".output.dense.bias"), &L->bo));
+  RR_TRY(up_f32(m, HT(m, a + ".output.LayerNorm.weight"), &L->ln1g));
+  RR_TRY(up_f32(m, HT(m, a + ".output.LayerNorm.bias"), &L->ln1b));
+  if (cross) {
+    const std::string c = p + ".crossattention";
+    RR_TRY(up_bf16(m, cat({&HT(m, c + ".self.query.weight")}, qs), &L->wq_c));
+    RR_TRY(up_f32(m, cat({&HT(m, c + ".self.query.bias")}, qs), &L->bq_c));
+    RR_TRY(up_bf16(m, cat({&HT(m, c + ".self.key.weight"), &HT(m, c + ".self.value.weight")}, 1.0f), &L->wkv_c));
+    RR_TRY(up_f32(m, cat({&HT(m, c + ".self.key.bias"), &HT(m, c + ".self.value.bias")}, 1.0f), &L->bkv_c));
+    RR_TRY(up_bf16(m, HT(m, c + ".output.dense.weight"), &L->wo_c));
+    RR_TRY(up_f32(m, HT(m, c + ".output.dense.bias"), &L->bo_c));
+    RR_TRY(up_f32(m, HT(m, c + ".output.LayerNorm.weight"), &L->lncg));
+    RR_TRY(up_f32(m, HT(m, c + ".output.LayerNorm.bias"), &L->lncb));
+  }
+  RR_TRY(up_bf16(m, HT(m, p + ".intermediate.dense.weight"), &L->w1));
+  RR_TRY(up_f32(m, HT(m, p + ".intermediate.dense.bias"), &L->b1));
+  RR_TRY(up_bf16(m, HT(m, p + ".output.dense.weight"), &L->w2));
+  RR_TRY(up_f32(m, HT(m, p + ".output.dense.bias"), &L->b2));
+  RR_TRY(up_f32(m, HT(m, p + ".output.LayerNorm.weight"), &L->ln2g));
+  RR_TRY(up_f32(m, HT(m, p + ".output.LayerNorm.bias"), &L->ln2b));
+  return RR_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------
+struct Bump {
+  char* base;
+  size_t off = 0;
+  explicit Bump(char* b) : base(b) {}
+  template <class T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Work {
+  float *h32, *pre, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w;
+  bf16_t *h16, *qkv, *ctx, *mid, *li16;
+  // vision
+  bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
+  float *vp_out32, *t32, *vpre, *a32, *a32b, *cpre, *c32, *m32, *mo32;
+};
+
+size_t imax(size_t a, size_t b) { return a > b ? a : b; }
+
+// Lays out the workspace for n local pairs of (at most) Bq queries; base == nullptr => size query.
+size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base, Work* w) {
+  Bump b(base);
+  const int P = vision ? c.prefix_len + c.n_patches : 0, T = S + P;
+  const size_t R = (size_t)n * S, RT = (size_t)n * T, Rm = imax(R, RT);
+  const size_t Hm = imax(c.hidden, c.ce_hidden), Im = imax(c.intermediate, c.ce_intermediate);
+  w->h32 = b.take<float>(Rm * Hm);
+  w->pre = b.take<float>(Rm * Hm);
+  w->h16 = b.take<bf16_t>(Rm * Hm);
+  w->qkv = b.take<bf16_t>(Rm * 3 * Hm);
+  w->ctx = b.take<bf16_t>(Rm * Hm);
+  w->mid = b.take<bf16_t>(Rm * Im);
+  w->li32 = b.take<float>(R * c.li_dim);
+  w->li16 = b.take<bf16_t>(RT * c.li_dim);
+  w->text_bias = b.take<float>(R);
+  w->ce_bias = b.take<float>(RT);
+  w->l1 = b.take<float>(n);
+  w->l2 = b.take<float>(n);
+  w->part_l = b.take<float>(Bq);
+  w->part_w = b.take<float>(Bq);
+  if (vision) {
+    const size_t Hh = c.hidden, np = c.n_patches, Vh = c.vision_hidden, D = c.li_dim, PL = c.prefix_len;
+    const size_t ca = (size_t)(S < c.cross_attn_len ? S : c.cross_attn_len);
+    const size_t nb = c.map_layers > 1 ? imax((size_t)n, (size_t)Bq) : (size_t)Bq;   // batches in the self-attn block
+    w->cls16 = b.take<bf16_t>((size_t)Bq * Vh);
+    w->vp_mid16 = b.take<bf16_t>((size_t)Bq * D * PL / 2);
+    w->vp_out32 = b.take<float>((size_t)Bq * D * PL);
+    w->pat16 = b.take<bf16_t>((size_t)Bq * np * Vh);
+    w->t32 = b.take<float>((size_t)Bq * np * Hh);
+    w->t16 = b.take<bf16_t>((size_t)Bq * np * Hh);
+    w->vqkv = b.take<bf16_t>(nb * np * 3 * Hh);
+    w->vctx = b.take<bf16_t>(nb * np * Hh);
+    w->vpre = b.take<float>(nb * np * Hh);
+    w->a32 = b.take<float>(nb * np * Hh);
+    w->a16 = b.take<bf16_t>(nb * np * Hh);
+    w->q_c = b.take<bf16_t>(nb * np * Hh);
+    w->enc16 = b.take<bf16_t>((size_t)n * ca * Hh);
+    w->kv_c = b.take<bf16_t>((size_t)n * ca * 2 * Hh);
+    w->cctx = b.take<bf16_t>((size_t)n * np * Hh);
+    w->a32b = b.take<float>((size_t)n * np * Hh);
+    w->cpre = b.take<float>((size_t)n * np * Hh);
+    w->c32 = b.take<float>((size_t)n * np * Hh);
+    w->c16 = b.take<bf16_t>((size_t)n * np * Hh);
+    w->vmid = b.take<bf16_t>((size_t)n * np * c.intermediate);
+    w->m32 = b.take<float>((size_t)n * np * Hh);
+    w->m16 = b.take<bf16_t>((size_t)n * np * Hh);
+    w->mo32 = b.take<float>((size_t)n * np * D);
+  }
+  return (b.off + 255) & ~(size_t)255;
+}
+
+int ensure_ws(rr_model* m, size_t bytes, hipStream_t st) {
+  if (bytes <= m->ws_cap) return RR_OK;
+  if (m->ws) {
+    RR_HIP(m, hipStreamSynchronize(st));
+    RR_HIP(m, hipFree(m->ws));
+    m->ws = nullptr;
+    m->ws_cap = 0;
+  }
+  RR_HIP(m, hipMalloc((void**)&m->ws, bytes));
+  m->ws_cap = bytes;
+  return RR_OK;
+}
+
+double gemm_flops(double M, double N, double K) { return 2.0 * M * N * K; }
+double gemm_bytes(double M, double N, double K, double out_elt) { return 2.0 * (M * K + N * K) + out_elt * M * N; }
+
+#define RR_GEMM(m, st, A, lda, W, bias, resid, ldr, C, ldc, M, N, K, epi, outb)                         \
+  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, outb) + (((const void*)(resid) != nullptr) ? 4.0 * (M) * (N) : 0.0), \
+         rr_launch_gemm(A, lda, W, K, bias, resid, ldr, C, ldc, M, N, K, epi, st))
+
+// One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
+int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
+              const float* key_bias, Work& w) {
+  const int rows = batch * Tseq;
+  RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
+  RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
+         rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
+                             Tseq, w.ctx, Hd, st));
+  RR_GEMM(m, st, w.ctx, Hd, L.wo, L.bo, w.h32, Hd, w.pre, Hd, rows, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
+  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
+         rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, st));
+  RR_GEMM(m, st, w.h16, Hd, L.w1, L.b1, nullptr, 0, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
+  RR_GEMM(m, st, w.mid, I, L.w2, L.b2, w.h32, Hd, w.pre, Hd, rows, Hd, I, EPI_BIAS_RESID_F32, 4.0);
+  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
+         rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, st));
+  return RR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rr_version(void) { return "librerank_mi355 0.1.0 (gfx950, abi 1)"; }
+
+const char* rr_status_string(int s) {
+  switch (s) {
+    case RR_OK: return "ok";
+    case RR_ERR_BAD_ARG: return "bad argument";
+    case RR_ERR_BAD_SHAPE: return "bad shape";
+    case RR_ERR_BAD_DTYPE: return "bad dtype";
+    case RR_ERR_UNSUPPORTED: return "unsupported configuration";
+    case RR_ERR_HIP: return "HIP runtime error";
+    case RR_ERR_OOM: return "out of device memory";
+    case RR_ERR_MISSING_WEIGHT: return "missing weight";
+    case RR_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+static thread_local std::string g_create_err;
+
+int rr_create(const rr_config* cfg, rr_handle* out) {
+  if (!cfg || !out) return RR_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->abi_version != RR_ABI_VERSION) { g_create_err = "abi_version mismatch"; return RR_ERR_BAD_ARG; }
+  auto bad = [&](const char* why) { g_create_err = why; return RR_ERR_UNSUPPORTED; };
+  const rr_config& c = *cfg;
+  if (c.hidden <= 0 || c.heads <= 0 || c.hidden != c.heads * 64) return bad("text encoder head dim must be 64");
+  if (c.ce_hidden <= 0 || c.ce_heads <= 0 || c.ce_hidden != c.ce_heads * 64) return bad("cross encoder head dim must be 64");
+  if (c.hidden % 64 || c.intermediate % 64 || c.ce_hidden % 64 || c.ce_intermediate % 64 || c.li_dim % 64)
+    return bad("hidden/intermediate/li_dim must be multiples of 64");
+  if (c.hidden > 2048 || c.ce_hidden > 2048 || c.li_dim > 2048) return bad("row length above 2048 not supported");
+  if (c.layers < 0 || c.ce_layers < 0 || c.vocab_size <= 0 || c.max_pos <= 0 || c.ce_max_pos <= 0 || c.type_vocab <= 0)
+    return bad("bad layer/vocab/position counts");
+  if (c.loss_kind < 0 || c.loss_kind > 2) return bad("unknown loss_kind");
+  if (c.has_vision) {
+    if (c.vision_hidden % 64 || c.prefix_len <= 0 || c.n_patches <= 0 || c.map_layers < 0 || c.cross_attn_len <= 0 ||
+        (c.li_dim * c.prefix_len / 2) % 64)
+      return bad("bad vision configuration");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c.device < 0 || c.device >= ndev) {
+    g_create_err = "no HIP device visible (librerank_mi355 has no CPU path)";
+    return RR_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) return RR_ERR_HIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_err = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+    return RR_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(c.device) != hipSuccess) return RR_ERR_HIP;
+  rr_model* m = new rr_model();
+  m->cfg = c;
+  build_required(m);
+  *out = m;
+  return RR_OK;
+}
+
+const char* rr_last_error(rr_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int rr_destroy(rr_handle h) {
+  if (!h) return RR_ERR_BAD_ARG;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->dev_allocs) (void)hipFree(p);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->tap_text) (void)hipFree(h->tap_text);
+  for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  delete h;
+  return RR_OK;
+}
+
+int rr_num_required_weights(rr_handle h) { return h ? (int)h->required_order.size() : RR_ERR_BAD_ARG; }
+const char* rr_required_weight_name(rr_handle h, int i) {
+  if (!h || i < 0 || i >= (int)h->required_order.size()) return nullptr;
+  return h->required_order[i].c_str();
+}
+
+int rr_load_weight(rr_handle h, const char* name, const void* data, int dtype, int ndim, const int64_t* shape,
+                   int* known) {
+  if (!h || !name || !data || ndim < 0 || (ndim > 0 && !shape)) return fail(h, RR_ERR_BAD_ARG, "rr_load_weight: null argument");
+  if (h->finalized) return fail(h, RR_ERR_BAD_ARG, "rr_load_weight after rr_finalize_weights");
+  auto it = h->required.find(name);
+  if (known) *known = it != h->required.end();
+  if (it == h->required.end()) return RR_OK;   // strict=False semantics: ignore tensors the path does not read
+  if (dtype != RR_F32 && dtype != RR_BF16 && dtype != RR_F16) return fail(h, RR_ERR_BAD_DTYPE, "%s: dtype %d", name, dtype);
+  const auto& want = it->second;
+  bool ok = (int)want.size() == ndim;
+  size_t n = 1;
+  for (int i = 0; ok && i < ndim; ++i) { ok = want[i] == shape[i]; n *= (size_t)shape[i]; }
+  if (!ok) {
+    std::string ws, gs;
+    for (auto d : want) ws += std::to_string(d) + ",";
+    for (int i = 0; i < ndim; ++i) gs += std::to_string(shape[i]) + ",";
+    return fail(h, RR_ERR_BAD_SHAPE, "%s: expected shape [%s] got [%s]", name, ws.c_str(), gs.c_str());
+  }
+  HostTensor t;
+  t.shape = want;
+  t.data.resize(n);
+  if (dtype == RR_F32) memcpy(t.data.data(), data, n * 4);
+  else if (dtype == RR_BF16) for (size_t i = 0; i < n; ++i) t.data[i] = host_bf2f(((const uint16_t*)data)[i]);
+  else for (size_t i = 0; i < n; ++i) t.data[i] = host_h2f(((const uint16_t*)data)[i]);
+  h->host[name] = std::move(t);
+  return RR_OK;
+}
+
+int rr_finalize_weights(rr_handle h) {
+  if (!h) return RR_ERR_BAD_ARG;
+  if (h->finalized) return RR_OK;
+  for (const auto& n : h->required_order)
+    if (!h->host.count(n)) return fail(h, RR_ERR_MISSING_WEIGHT, "missing weight: %s", n.c_str());
+  rr_model* m = h;
+  const rr_config& c = m->cfg;
+  RR_HIP(m, hipSetDevice(c.device));
+  std::string p = "context_text_encoder.bert_model";
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.word_embeddings.weight"), &m->word));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.position_embeddings.weight"), &m->pos));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.token_type_embeddings.weight"), &m->type));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.weight"), &m->emb_g));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.bias"), &m->emb_b));
+  m->text_layers.resize(c.layers);
+  for (int i = 0; i < c.layers; ++i)
+    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.heads, c.hidden, false, &m->text_layers[i]));
+  RR_TRY(up_bf16(m, HT(m, "context_text_encoder_linear.weight"), &m->w_li));
+  if (c.has_vision) {
+    RR_TRY(up_bf16(m, HT(m, "context_vision_projection.model.0.weight"), &m->w_vp0));
+    RR_TRY(up_f32(m, HT(m, "context_vision_projection.model.0.bias"), &m->b_vp0));
+    RR_TRY(up_bf16(m, HT(m, "context_vision_projection.model.2.weight"), &m->w_vp2));
+    RR_TRY(up_f32(m, HT(m, "context_vision_projection.model.2.bias"), &m->b_vp2));
+    RR_TRY(up_bf16(m, HT(m, "transformer_mapping_input_linear.weight"), &m->w_min));
+    RR_TRY(up_f32(m, HT(m, "transformer_mapping_input_linear.bias"), &m->b_min));
+    m->map_layers.resize(c.map_layers);
+    for (int i = 0; i < c.map_layers; ++i)
+      RR_TRY(pack_layer(m, "transformer_mapping_network.layer." + std::to_string(i), c.heads, c.hidden, true,
+                        &m->map_layers[i]));
+    RR_TRY(up_bf16(m, HT(m, "transformer_mapping_output_linear.weight"), &m->w_mout));
+    RR_TRY(up_f32(m, HT(m, "transformer_mapping_output_linear.bias"), &m->b_mout));
+  }
+  RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
+  RR_TRY(up_f32(m, HT(m, "cross_encoder_input_mapping.bias"), &m->b_cemap));
+  p = "reranker.bert_model";
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.position_embeddings.weight"), &m->ce_pos));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.token_type_embeddings.weight"), &m->ce_type));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.weight"), &m->ce_emb_g));
+  RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.bias"), &m->ce_emb_b));
+  m->ce_layers.resize(c.ce_layers);
+  for (int i = 0; i < c.ce_layers; ++i)
+    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i]));
+  RR_TRY(up_f32(m, HT(m, "reranker.classifier1.weight"), &m->cls1_w));
+  RR_TRY(up_f32(m, HT(m, "reranker.classifier1.bias"), &m->cls1_b));
+  RR_TRY(up_f32(m, HT(m, "reranker.classifier2.weight"), &m->cls2_w));
+  RR_TRY(up_f32(m, HT(m, "reranker.classifier2.bias"), &m->cls2_b));
+  m->host.clear();
+  m->finalized = true;
+  return RR_OK;
+}
+
+int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len) {
+  if (!h || n_pairs <= 0 || seq_len <= 0) return RR_ERR_BAD_ARG;
+  Work w;
+  return (int64_t)layout(h->cfg, n_pairs, n_pairs, seq_len, h->cfg.has_vision != 0, nullptr, &w);
+}
+
+int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,
+            float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  if (!h || !logits) return fail(h, RR_ERR_BAD_ARG, "rr_head: null argument");
+  if (Bq <= 0 || K <= 0) return fail(h, RR_ERR_BAD_SHAPE, "rr_head: Bq=%d K=%d", Bq, K);
+  if (K > 4096) return fail(h, RR_ERR_UNSUPPORTED, "rr_head: K=%d > 4096", K);
+  const rr_config& c = h->cfg;
+  if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && labels)
+    return fail(h, RR_ERR_BAD_ARG, "Labels should not be provided for negative sampling loss function");
+  if (c.loss_kind == RR_LOSS_2H_BCE && !logits2) return fail(h, RR_ERR_BAD_ARG, "rr_head: 2H_BCE needs logits2 (first head)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  RR_HIP(h, hipSetDevice(c.device));
+  Work w;
+  const size_t need = layout(c, 1, Bq, 8, false, nullptr, &w);
+  RR_TRY(ensure_ws(h, need, st));
+  layout(c, 1, Bq, 8, false, h->ws, &w);
+  const int has_pw = !std::isnan(c.pos_weight);
+  RR_RUN(h, st, RR_K_HEAD, 0.0, 12.0 * Bq * K,
+         rr_launch_head(logits, logits2, labels, Bq, K, c.loss_kind, has_pw ? c.pos_weight : 1.0f, has_pw, scores_out,
+                        order_out, loss_out, w.part_l, w.part_w, st));
+  return RR_OK;
+}
+
+int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+               const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels,
+               int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+               float* scores_out, int32_t* order_out, void* hip_stream) {
+  if (!h) return RR_ERR_BAD_ARG;
+  rr_model* m = h;
+  const rr_config& c = m->cfg;
+  if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_forward before rr_finalize_weights");
+  if (!input_ids || !attention_mask || !logits_out) return fail(m, RR_ERR_BAD_ARG, "rr_forward: null input_ids/attention_mask/logits_out");
+  if (Bq <= 0 || K <= 0 || S <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_forward: Bq=%d K=%d S=%d", Bq, K, S);
+  const int N = Bq * K;
+  if (pair_begin < 0 || pair_end > N || pair_begin >= pair_end)
+    return fail(m, RR_ERR_BAD_SHAPE, "rr_forward: pair slice [%d,%d) outside [0,%d)", pair_begin, pair_end, N);
+  if (S > c.max_pos) return fail(m, RR_ERR_BAD_SHAPE, "seq_len %d exceeds max_position_embeddings %d", S, c.max_pos);
+  const bool vision = image_cls != nullptr || image_patches != nullptr;
+  if (vision && !(image_cls && image_patches)) return fail(m, RR_ERR_BAD_ARG, "image_cls and image_patches must be given together");
+  if (vision && !c.has_vision) return fail(m, RR_ERR_UNSUPPORTED, "image features passed to a text_only model");
+  const int P = vision ? c.prefix_len + c.n_patches : 0, T = S + P;
+  if (T > c.ce_max_pos)
+    return fail(m, RR_ERR_BAD_SHAPE, "cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", T, c.ce_max_pos);
+  const bool full = pair_begin == 0 && pair_end == N;
+  if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && labels)
+    return fail(m, RR_ERR_BAD_ARG, "Labels should not be provided for negative sampling loss function");
+  if (!full && (loss_out || scores_out || order_out))
+    return fail(m, RR_ERR_BAD_ARG, "loss/scores/order need the full pair range; use rr_head after gathering logits");
+  if (c.loss_kind == RR_LOSS_2H_BCE && full && (loss_out || scores_out) && !logits2_out)
+    return fail(m, RR_ERR_BAD_ARG, "2H_BCE head needs logits2_out");
+  if (K > 4096 && (loss_out || scores_out || order_out)) return fail(m, RR_ERR_UNSUPPORTED, "K=%d > 4096", K);
+
+  hipStream_t st = (hipStream_t)hip_stream;
+  RR_HIP(m, hipSetDevice(c.device));
+  const int n = pair_end - pair_begin;
+  const int q_lo = pair_begin / K, q_hi = (pair_end - 1) / K, nq = q_hi - q_lo + 1;   // queries touched by the slice
+  Work w;
+  const size_t need = layout(c, n, Bq, S, vision, nullptr, &w);
+  RR_TRY(ensure_ws(m, need, st));
+  layout(c, n, Bq, S, vision, m->ws, &w);
+  m->last_stream = st;
+
+  const int Hd = c.hidden, I = c.intermediate, D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate;
+  const int R = n * S, RT = n * T;
+  const int64_t* ids = input_ids + (size_t)pair_begin * S;
+  const int64_t* am = attention_mask + (size_t)pair_begin * S;
+  const int64_t* tts = token_type_ids ? token_type_ids + (size_t)pair_begin * S : nullptr;
+
+  // ---- masks -> additive key bias (text: tokenizer mask; cross encoder: id != 0, vision = 1)
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 16.0 * R + 8.0 * RT, rr_launch_key_bias(ids, am, n, S, T, w.text_bias, w.ce_bias, st));
+  // ---- text encoder (FLMRTextModel = BertModel)
+  RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * R * Hd,
+         rr_launch_embed_ln(ids, tts, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps, R, S, Hd, c.vocab_size,
+                            c.type_vocab, w.h32, w.h16, st));
+  for (int l = 0; l < c.layers; ++l)
+    RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w));
+  if (m->debug) {
+    const size_t el = (size_t)R * Hd;
+    if (m->tap_text_elems < el) {
+      if (m->tap_text) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->tap_text)); m->tap_text = nullptr; }
+      RR_HIP(m, hipMalloc((void**)&m->tap_text, el * 4));
+    }
+    m->tap_text_elems = el;
+    RR_HIP(m, hipMemcpyAsync(m->tap_text, w.h32, el * 4, hipMemcpyDeviceToDevice, st));
+  }
+  // ---- 768 -> 128 projection (no bias), mask, L2 normalise -> li16[:, :S]
+  RR_GEMM(m, st, w.h16, Hd, m->w_li, nullptr, nullptr, 0, w.li32, D, R, D, Hd, EPI_BIAS_F32, 4.0);
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * R * D + 8.0 * R,
+         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, st));
+
+  if (vision) {
+    const int np = c.n_patches, PL = c.prefix_len, Vh = c.vision_hidden, mid = D * PL / 2, outd = D * PL;
+    const float* cls = image_cls + (size_t)q_lo * Vh;
+    const float* pat = image_patches + (size_t)q_lo * np * Vh;
+    // prefix MLP (per query): Linear -> Tanh -> Linear -> view [PL, D]
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * Vh, rr_launch_f32_to_bf16(cls, w.cls16, (size_t)nq * Vh, st));
+    RR_GEMM(m, st, w.cls16, Vh, m->w_vp0, m->b_vp0, nullptr, 0, w.vp_mid16, mid, nq, mid, Vh, EPI_BIAS_TANH_BF16, 2.0);
+    RR_GEMM(m, st, w.vp_mid16, mid, m->w_vp2, m->b_vp2, nullptr, 0, w.vp_out32, outd, nq, outd, mid, EPI_BIAS_F32, 4.0);
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * PL * D,
+           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, st));
+    // mapping network: input linear + self-attention block depend on the image only => per query
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, st));
+    RR_GEMM(m, st, w.pat16, Vh, m->w_min, m->b_min, nullptr, 0, w.t32, Hd, nq * np, Hd, Vh, EPI_BIAS_F32, 4.0);
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Hd, rr_launch_f32_to_bf16(w.t32, w.t16, (size_t)nq * np * Hd, st));
+    const int ca = S < c.cross_attn_len ? S : c.cross_attn_len;
+    // pair-specific text states the cross-attention reads: first `ca` rows of every pair (rerank_model.py:438-442)
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * ca * Hd,
+           rr_launch_gather_rows(w.h16, w.enc16, n, ca, S, Hd * 2, 0, 1, 0, st));
+    const float* tin32 = w.t32;    // [nq*np, Hd] (per query) for layer 0; per pair afterwards
+    const bf16_t* tin16 = w.t16;
+    for (int l = 0; l < c.map_layers; ++l) {
+      const LayerW& L = m->map_layers[l];
+      const bool per_query = (l == 0);
+      const int bt = per_query ? nq : n;           // batches entering this layer
+      // self-attention (no mask: the reference passes attention_mask=None, rerank_model.py:450-454)
+      RR_GEMM(m, st, tin16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.vqkv, 3 * Hd, bt * np, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
+      RR_RUN(m, st, RR_K_ATTENTION, 4.0 * bt * (double)np * np * Hd, 8.0 * bt * np * Hd,
+             rr_launch_attention(w.vqkv, 3 * Hd, 1, 0, w.vqkv + Hd, w.vqkv + 2 * Hd, 3 * Hd, nullptr, bt, c.heads, np, np,
+                                 w.vctx, Hd, st));
+      RR_GEMM(m, st, w.vctx, Hd, L.wo, L.bo, tin32, Hd, w.vpre, Hd, bt * np, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * bt * np * Hd,
+             rr_launch_layernorm(w.vpre, L.ln1g, L.ln1b, c.ln_eps, bt * np, Hd, w.a32, w.a16, st));
+      // cross-attention: queries from `a`, keys/values from the pair's first `ca` text states
+      RR_GEMM(m, st, w.a16, Hd, L.wq_c, L.bq_c, nullptr, 0, w.q_c, Hd, bt * np, Hd, Hd, EPI_BIAS_BF16, 2.0);
+      RR_GEMM(m, st, w.enc16, Hd, L.wkv_c, L.bkv_c, nullptr, 0, w.kv_c, 2 * Hd, n * ca, 2 * Hd, Hd, EPI_BIAS_BF16, 2.0);
+      RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)np * ca * Hd, 2.0 * n * (2.0 * np + 2.0 * ca) * Hd,
+             rr_launch_attention(w.q_c, Hd, per_query ? K : 1, per_query ? pair_begin - q_lo * K : 0, w.kv_c,
+                                 w.kv_c + Hd, 2 * Hd, nullptr, n, c.heads, np, ca, w.cctx, Hd, st));
+      const float* resid = w.a32;
+      if (per_query) {   // broadcast the per-query residual to the pairs
+        RR_RUN(m, st, RR_K_TAIL, 0.0, 8.0 * n * np * Hd,
+               rr_launch_gather_rows(w.a32, w.a32b, n, np, np, Hd * 4, pair_begin, K, q_lo, st));
+        resid = w.a32b;
+      }
+      RR_GEMM(m, st, w.cctx, Hd, L.wo_c, L.bo_c, resid, Hd, w.cpre, Hd, n * np, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * np * Hd,
+             rr_launch_layernorm(w.cpre, L.lncg, L.lncb, c.ln_eps, n * np, Hd, w.c32, w.c16, st));
+      RR_GEMM(m, st, w.c16, Hd, L.w1, L.b1, nullptr, 0, w.vmid, I, n * np, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
+      RR_GEMM(m, st, w.vmid, I, L.w2, L.b2, w.c32, Hd, w.cpre, Hd, n * np, Hd, I, EPI_BIAS_RESID_F32, 4.0);
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * np * Hd,
+             rr_launch_layernorm(w.cpre, L.ln2g, L.ln2b, c.ln_eps, n * np, Hd, w.m32, w.m16, st));
+      tin32 = w.m32;
+      tin16 = w.m16;
+    }
+    if (c.map_layers == 0) {   // degenerate: no mapping layer, features are per query -> broadcast
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * np * Hd,
+             rr_launch_gather_rows(w.t16, w.m16, n, np, np, Hd * 2, pair_begin, K, q_lo, st));
+    }
+    RR_GEMM(m, st, w.m16, Hd, m->w_mout, m->b_mout, nullptr, 0, w.mo32, D, n * np, D, Hd, EPI_BIAS_F32, 4.0);
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * np * D,
+           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, st));
+  }
+  m->tap_li = w.li16;
+  m->tap_li_elems = (size_t)RT * D;
+
+  // ---- cross encoder: Linear(D -> Hc) -> embeddings(inputs_embeds) -> Lc layers -> CLS -> heads
+  RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
+         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, st));
+  for (int l = 0; l < c.ce_layers; ++l)
+    RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w));
+  m->tap_ce = w.h32;
+  m->tap_ce_elems = (size_t)RT * Hc;
+
+  // classifier1 -> "logits", classifier2 -> "logits_secondary" (utils.py:105-108).  For 2H_BCE the ranked
+  // logit is the second head (rerank_model.py:589-590).
+  float* out_a = logits_out + pair_begin;
+  float* out_b = logits2_out ? logits2_out + pair_begin : w.l2;
+  if (c.loss_kind == RR_LOSS_2H_BCE) {
+    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
+           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
+  } else {
+    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
+           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls1_w, m->cls1_b, m->cls2_w, m->cls2_b, out_a, out_b, st));
+  }
+  if (full && (loss_out || scores_out || order_out)) {
+    const int has_pw = !std::isnan(c.pos_weight);
+    RR_RUN(m, st, RR_K_HEAD, 0.0, 12.0 * N,
+           rr_launch_head(logits_out, c.loss_kind == RR_LOSS_2H_BCE ? logits2_out : nullptr, labels, Bq, K, c.loss_kind,
+                          has_pw ? c.pos_weight : 1.0f, has_pw, scores_out, order_out, loss_out, w.part_l, w.part_w, st));
+  }
+  return RR_OK;
+}
+
+int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems) {
+  if (!h || !name || !host_out) return RR_ERR_BAD_ARG;
+  if (hipSetDevice(h->cfg.device) != hipSuccess) return RR_ERR_HIP;
+  if (hipStreamSynchronize(h->last_stream) != hipSuccess) return fail(h, RR_ERR_HIP, "stream sync failed");
+  const std::string n = name;
+  if (n == "text_hidden") {
+    if (!h->tap_text) return fail(h, RR_ERR_BAD_ARG, "text_hidden tap needs rr_set_debug(1) before rr_forward");
+    if ((int64_t)h->tap_text_elems > max_elems) return fail(h, RR_ERR_BAD_SHAPE, "buffer too small");
+    if (hipMemcpy(host_out, h->tap_text, h->tap_text_elems * 4, hipMemcpyDeviceToHost) != hipSuccess) return RR_ERR_HIP;
+    return (int64_t)h->tap_text_elems;
+  }
+  if (n == "ce_hidden") {
+    if (!h->tap_ce || (int64_t)h->tap_ce_elems > max_elems) return fail(h, RR_ERR_BAD_SHAPE, "no tap / buffer too small");
+    if (hipMemcpy(host_out, h->tap_ce, h->tap_ce_elems * 4, hipMemcpyDeviceToHost) != hipSuccess) return RR_ERR_HIP;
+    return (int64_t)h->tap_ce_elems;
+  }
+  if (n == "late_interaction") {
+    if (!h->tap_li || (int64_t)h->tap_li_elems > max_elems) return fail(h, RR_ERR_BAD_SHAPE, "no tap / buffer too small");
+    std::vector<uint16_t> t(h->tap_li_elems);
+    if (hipMemcpy(t.data(), h->tap_li, t.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return RR_ERR_HIP;
+    for (size_t i = 0; i < t.size(); ++i) host_out[i] = host_bf2f(t[i]);
+    return (int64_t)t.size();
+  }
+  return fail(h, RR_ERR_BAD_ARG, "unknown tap %s", name);
+}
+
+int rr_set_debug(rr_handle h, int on) {
+  if (!h) return RR_ERR_BAD_ARG;
+  h->debug = on != 0;
+  return RR_OK;
+}
+
+int rr_set_profiling(rr_handle h, int on) {
+  if (!h) return RR_ERR_BAD_ARG;
+  h->profiling = on != 0;
+  return RR_OK;
+}
+
+int rr_get_profile(rr_handle h, rr_profile* out, int reset) {
+  if (!h || !out) return RR_ERR_BAD_ARG;
+  RR_HIP(h, hipSetDevice(h->cfg.device));
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    ProfEvent& e = h->ev_pool[i];
+    RR_HIP(h, hipEventSynchronize(e.b));
+    float ms = 0.f;
+    RR_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+    h->prof.ms[e.kclass] += ms;
+  }
+  h->ev_used = 0;
+  *out = h->prof;
+  if (reset) h->prof = rr_profile{};
+  return RR_OK;
+}
+
+// ---- stand-alone operators ---------------------------------------------------------------------
+int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue,
+                    void* out, void* hip_stream) {
+  if (!A || !W || !out) return RR_ERR_BAD_ARG;
+  if (epilogue < 0 || epilogue > 3) return RR_ERR_BAD_ARG;
+  const int epi_map[4] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32, EPI_BIAS_TANH_BF16};
+  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, nullptr, 0, out, N, M, N, Kd, epi_map[epilogue], (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N,
+                         int Kd, float* out, void* hip_stream) {
+  if (!A || !W || !out || !resid) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, resid, N, out, N, M, N, Kd, EPI_BIAS_RESID_F32, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
+                         const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out,
+                         int out_stride, void* hip_stream) {
+  if (!q || !k || !v || !out) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_attention(q, q_stride, q_batch_div, 0, k, v, kv_stride, key_bias, B, heads, Tq, Tk, out,
+                                     out_stride, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                    float* out_f32, uint16_t* out_bf16, void* hip_stream) {
+  if (!x || !gamma || !beta || (!out_f32 && !out_bf16)) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_layernorm(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+}  // extern "C"

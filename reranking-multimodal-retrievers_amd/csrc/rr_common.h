@@ -1,0 +1,67 @@
+// Shared device/host helpers for librerank_mi355 (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bit pattern
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define RR_WAVE 64
+
+// ---- bf16 <-> f32 (round-to-nearest-even; NaN stays NaN via the plain cast, which hipcc
+// lowers to v_cvt_pk_bf16_f32 on gfx950 — MI355X_MICROARCH "Correctness boundaries").
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+  return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// LDS byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64 x bf16] tile image
+// (128-byte rows).  XOR with (row>>1)&7 keeps every ds_read_b128 lane group (16 rows of one
+// chunk column, cdna_hip_programming.md §2 / T2) on 16 distinct 16-byte slots of the
+// 256-byte bank row => conflict-free.
+__device__ __forceinline__ int swz128(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host-side launcher signatures (implemented in the .hip files) ---------------------------------
+enum GemmEpilogue {
+  EPI_BIAS_BF16 = 0,       // C = bf16(A W^T + b)
+  EPI_BIAS_GELU_BF16 = 1,  // C = bf16(gelu_erf(A W^T + b))
+  EPI_BIAS_F32 = 2,        // C = f32(A W^T + b)
+  EPI_BIAS_TANH_BF16 = 3,  // C = bf16(tanh(A W^T + b))
+  EPI_BIAS_RESID_F32 = 4   // C = f32(A W^T + b + R)
+};
+
+// A [M,Kd] bf16 (row stride lda), W [N,Kd] bf16 (row stride ldw), bias [N] f32 or null,
+// resid [M,N] f32 (row stride ldr, EPI 4) ; C row stride ldc (elements of its type).
+hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
+                          const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
+                          int epilogue, hipStream_t st);
+
+// Multi-head attention, head dim 64.  q rows: q + (bq*Tq + t)*q_stride + head*64, where
+// bq = (b + q_batch_off) / q_batch_div;  k,v rows: (b*Tk + t)*kv_stride + head*64;  key_bias [B,Tk] f32 additive
+// (0 valid, -1e30 masked) or null;  out rows: (b*Tq + t)*out_stride + head*64 (bf16).
+hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
+                               const bf16_t* v, int kv_stride, const float* key_bias, int B,
+                               int heads, int Tq, int Tk, bf16_t* out, int out_stride,
+                               hipStream_t st);
+
+hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                               int rows, int cols, float* out_f32, bf16_t* out_bf16, hipStream_t st);

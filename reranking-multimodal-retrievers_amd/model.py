@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's reranker plug-in interface, on top of librerank_mi355.so.
+
+Reference interface mirrored (paths relative to /root/reference/):
+  * plug-in construction `RerankerClass(reranker_config)` — src/executors/Reranker_base_executor.py:191-202
+  * `FullContextRerankModel.forward(query_text_sequences, query_pixel_values, context_text_sequences,
+     num_negative_examples, labels=None)` — src/models/rerank/rerank_model.py:523-591
+  * return `EasyDict(loss=<0-dim tensor>, logits=<tensor>)` consumed at Reranker_base_executor.py:922-927
+  * error behaviour: AssertionError on N != Bq*K / label count (rerank_model.py:527-529), ValueError for
+    labels with negative_sampling (utils.py:233), NotImplementedError for unsupported variants.
+
+Nothing here computes: tensors are only allocated and handed to the C ABI by address.  If the HIP
+library is missing, or no MI355X is visible, construction raises — there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+class RerankOutput(dict):
+    """EasyDict-style result: `.loss` (0-dim fp32 device tensor), `.logits` (fp32 device tensor)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    __setattr__ = dict.__setitem__
+
+
+def _get(cfg, name, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+# bert-base-uncased / PreFLMR ViT-B architecture (configuration_flmr.py:90-122,220-236,332-350)
+FLMR_DEFAULTS = dict(vocab_size=30522, hidden=768, layers=12, heads=12, intermediate=3072, max_pos=512,
+                     type_vocab=2, ln_eps=1e-12, li_dim=128, vision_hidden=768, prefix_len=32, n_patches=49,
+                     map_layers=1, cross_attn_len=32)
+CE_DEFAULTS = dict(ce_hidden=768, ce_heads=12, ce_intermediate=3072)   # cross_encoder_config_base = bert-base-uncased
+
+
+def make_arch(reranker_config=None, **overrides) -> dict:
+    """Architecture dict from a reference-style `reranker_config` (EasyDict/dict/object with
+    `cross_encoder_num_hidden_layers`, `cross_encoder_max_position_embeddings`, `loss_fn`, `pos_weight`,
+    ... — monoBERT_pointwise.jsonnet:111-122) plus optional `arch` overrides for the FLMR side."""
+    a = dict(FLMR_DEFAULTS)
+    a.update(CE_DEFAULTS)
+    a.update(ce_layers=_get(reranker_config, "cross_encoder_num_hidden_layers", 1),
+             ce_max_pos=_get(reranker_config, "cross_encoder_max_position_embeddings", 750),
+             loss_fn=_get(reranker_config, "loss_fn", "BCE"),
+             pos_weight=_get(reranker_config, "pos_weight", None),
+             has_vision=1)
+    a.update(_get(reranker_config, "arch", None) or {})
+    a.update(overrides)
+    return a
+
+
+def weight_spec(a: dict) -> List[tuple]:
+    """(name, shape, kind) of every tensor the path reads, named by the reference state_dict keys."""
+    H, I, D = a["hidden"], a["intermediate"], a["li_dim"]
+
+    def layer(p, Hh, Ii, cross):
+        out = []
+        for att in ["attention"] + (["crossattention"] if cross else []):
+            for n in ("query", "key", "value"):
+                out += [(f"{p}.{att}.self.{n}.weight", (Hh, Hh), "w"), (f"{p}.{att}.self.{n}.bias", (Hh,), "b")]
+            out += [(f"{p}.{att}.output.dense.weight", (Hh, Hh), "w"), (f"{p}.{att}.output.dense.bias", (Hh,), "b"),
+                    (f"{p}.{att}.output.LayerNorm.weight", (Hh,), "g"), (f"{p}.{att}.output.LayerNorm.bias", (Hh,), "b")]
+        out += [(f"{p}.intermediate.dense.weight", (Ii, Hh), "w"), (f"{p}.intermediate.dense.bias", (Ii,), "b"),
+                (f"{p}.output.dense.weight", (Hh, Ii), "w"), (f"{p}.output.dense.bias", (Hh,), "b"),
+                (f"{p}.output.LayerNorm.weight", (Hh,), "g"), (f"{p}.output.LayerNorm.bias", (Hh,), "b")]
+        return out
+
+    s = []
+    p = "context_text_encoder.bert_model"
+    s += [(f"{p}.embeddings.word_embeddings.weight", (a["vocab_size"], H), "e"),
+          (f"{p}.embeddings.position_embeddings.weight", (a["max_pos"], H), "e"),
+          (f"{p}.embeddings.token_type_embeddings.weight", (a["type_vocab"], H), "e"),
+          (f"{p}.embeddings.LayerNorm.weight", (H,), "g"), (f"{p}.embeddings.LayerNorm.bias", (H,), "b")]
+    for i in range(a["layers"]):
+        s += layer(f"{p}.encoder.layer.{i}", H, I, False)
+    s += [("context_text_encoder_linear.weight", (D, H), "w")]
+    if a["has_vision"]:
+        Vh, PL = a["vision_hidden"], a["prefix_len"]
+        s += [("context_vision_projection.model.0.weight", (D * PL // 2, Vh), "w"),
+              ("context_vision_projection.model.0.bias", (D * PL // 2,), "b"),
+              ("context_vision_projection.model.2.weight", (D * PL, D * PL // 2), "w"),
+              ("context_vision_projection.model.2.bias", (D * PL,), "b"),
+              ("transformer_mapping_input_linear.weight", (H, Vh), "w"),
+              ("transformer_mapping_input_linear.bias", (H,), "b")]
+        for i in range(a["map_layers"]):
+            s += layer(f"transformer_mapping_network.layer.{i}", H, I, True)
+        s += [("transformer_mapping_output_linear.weight", (D, H), "w"),
+              ("transformer_mapping_output_linear.bias", (D,), "b")]
+    Hc, Ic = a["ce_hidden"], a["ce_intermediate"]
+    s += [("cross_encoder_input_mapping.weight", (Hc, D), "w"), ("cross_encoder_input_mapping.bias", (Hc,), "b")]
+    p = "reranker.bert_model"
+    s += [(f"{p}.embeddings.position_embeddings.weight", (a["ce_max_pos"], Hc), "e"),
+          (f"{p}.embeddings.token_type_embeddings.weight", (a["type_vocab"], Hc), "e"),
+          (f"{p}.embeddings.LayerNorm.weight", (Hc,), "g"), (f"{p}.embeddings.LayerNorm.bias", (Hc,), "b")]
+    for i in range(a["ce_layers"]):
+        s += layer(f"{p}.encoder.layer.{i}", Hc, Ic, False)
+    s += [("reranker.classifier1.weight", (1, Hc), "w"), ("reranker.classifier1.bias", (1,), "b"),
+          ("reranker.classifier2.weight", (1, Hc), "w"), ("reranker.classifier2.bias", (1,), "b")]
+    return s
+
+
+def synthetic_state_dict(a: dict, seed: int = 0, hf_init: bool = True) -> Dict[str, torch.Tensor]:
+    """Seeded random-init weights (HF init: N(0, 0.02) matrices/embeddings, LN 1/0, zero biases —
+    modeling_flmr.py:199-214) for benchmarks: there are no checkpoints in the build environment.
+    Each tensor has its own generator seeded by (seed, index), identical to the test oracle's scheme so the
+    CPU baseline can be fed the very same weights."""
+    w = {}
+    for idx, (name, shape, kind) in enumerate(weight_spec(a)):
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        if kind in ("w", "e"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif kind == "g":
+            t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.zeros(shape) if hf_init else 0.05 * torch.randn(shape, generator=g)
+        w[name] = t
+    return w
+
+
+class RerankEngine:
+    """Owns one `rr_handle` (one model replica on one GPU)."""
+
+    def __init__(self, arch: dict, device: Optional[torch.device] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("rmr_amd needs an MI355X (gfx950) visible to HIP; there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.arch = dict(arch)
+        c = L.RRConfig()
+        c.abi_version = L.RR_ABI_VERSION
+        for k in ("vocab_size", "hidden", "layers", "heads", "intermediate", "max_pos", "type_vocab", "li_dim",
+                  "ce_hidden", "ce_layers", "ce_heads", "ce_intermediate", "ce_max_pos", "has_vision",
+                  "vision_hidden", "prefix_len", "n_patches", "map_layers", "cross_attn_len"):
+            setattr(c, k, int(arch[k]))
+        c.ln_eps = float(arch["ln_eps"])
+        if arch["loss_fn"] not in L.LOSS_KINDS:
+            raise ValueError(f"Unknown loss function {arch['loss_fn']}")        # utils.py:222-223
+        c.loss_kind = L.LOSS_KINDS[arch["loss_fn"]]
+        c.pos_weight = float("nan") if arch.get("pos_weight") is None else float(arch["pos_weight"])
+        c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p()
+        L.check(self.lib.rr_create(C.byref(c), C.byref(h)), None, "rr_create")
+        self.h = h
+        self.finalized = False
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.rr_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    # ---- weights ------------------------------------------------------------------------------
+    def required_weight_names(self) -> List[str]:
+        n = self.lib.rr_num_required_weights(self.h)
+        return [self.lib.rr_required_weight_name(self.h, i).decode() for i in range(n)]
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False, prefix: str = "") -> List[str]:
+        """Feed a reference-named state_dict (Lightning ckpt keys carry a `reranker.` executor prefix:
+        pass prefix="reranker.").  Unknown keys are ignored like load_state_dict(strict=False)
+        (Reranker_base_executor.py:366-381); missing required tensors raise KeyError."""
+        unexpected = []
+        for k, t in sd.items():
+            if prefix:
+                if not k.startswith(prefix):
+                    unexpected.append(k)
+                    continue
+                k = k[len(prefix):]
+            t = t.detach().to("cpu").contiguous()
+            if t.dtype == torch.float32:
+                dt = L.RR_F32
+            elif t.dtype == torch.bfloat16:
+                dt = L.RR_BF16
+            elif t.dtype == torch.float16:
+                dt = L.RR_F16
+            else:
+                raise ValueError(f"{k}: unsupported dtype {t.dtype}")
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            known = C.c_int(0)
+            L.check(self.lib.rr_load_weight(self.h, k.encode(), t.data_ptr(), dt, t.dim(), shape, C.byref(known)),
+                    self.h, "rr_load_weight")
+            if not known.value:
+                unexpected.append(k)
+        if strict and unexpected:
+            raise KeyError(f"unexpected keys: {unexpected[:5]}...")
+        L.check(self.lib.rr_finalize_weights(self.h), self.h, "rr_finalize_weights")
+        self.finalized = True
+        return unexpected
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                    token_type_ids: Optional[torch.Tensor], Bq: int, K: int,
+                    image_cls: Optional[torch.Tensor] = None, image_patches: Optional[torch.Tensor] = None,
+                    labels: Optional[torch.Tensor] = None, want_scores: bool = False, want_order: bool = False,
+                    pair_range: Optional[Sequence[int]] = None, want_loss: bool = True):
+        """One pass over the tokenised pair batch.  All tensors live on `self.device`.
+        Returns dict(logits [N] fp32, logits2 [N], loss 0-dim | None, scores | None, order [Bq,K] | None)."""
+        dev = self.device
+        N = input_ids.shape[0]
+        assert N == Bq * K, f"expanded batch {Bq}*{K} != {N}"                 # rerank_model.py:527
+        S = input_ids.shape[1]
+        for t in (input_ids, attention_mask) + ((token_type_ids,) if token_type_ids is not None else ()):
+            if t.dtype != torch.int64 or t.device != dev or tuple(t.shape) != (N, S):
+                raise ValueError("input_ids/attention_mask/token_type_ids must be int64 [N,S] on the model device")
+        if labels is not None:
+            assert labels.numel() == N, "len(labels) != expanded batch size"   # rerank_model.py:528-529
+            labels = labels.to(device=dev, dtype=torch.float32).contiguous()
+        if image_cls is not None:
+            image_cls = image_cls.to(device=dev, dtype=torch.float32).contiguous()
+            image_patches = image_patches.to(device=dev, dtype=torch.float32).contiguous()
+            if image_cls.shape[0] != Bq or image_patches.shape[0] != Bq:
+                raise AssertionError("image features must be per query: [Bq, ...]")
+        pb, pe = (0, N) if pair_range is None else (int(pair_range[0]), int(pair_range[1]))
+        full = pb == 0 and pe == N
+        logits = torch.empty(N, dtype=torch.float32, device=dev)
+        logits2 = torch.empty(N, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev) if (full and want_loss) else None
+        scores = torch.empty(N, dtype=torch.float32, device=dev) if (full and want_scores) else None
+        order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if (full and want_order) else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(self.lib.rr_forward(self.h, L.ptr(input_ids), L.ptr(attention_mask), L.ptr(token_type_ids),
+                                    L.ptr(image_cls), L.ptr(image_patches), Bq, K, S, L.ptr(labels), pb, pe,
+                                    L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores), L.ptr(order),
+                                    stream), self.h, "rr_forward")
+        return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
+
+    def head(self, logits: torch.Tensor, logits2: Optional[torch.Tensor], labels: Optional[torch.Tensor], Bq: int,
+             K: int, want_scores: bool = False, want_order: bool = True):
+        """Scoring head on complete logits (after the cross-rank all-gather)."""
+        dev = self.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        scores = torch.empty(Bq * K, dtype=torch.float32, device=dev) if want_scores else None
+        order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if want_order else None
+        if labels is not None:
+            labels = labels.to(device=dev, dtype=torch.float32).contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(self.lib.rr_head(self.h, L.ptr(logits), L.ptr(logits2), L.ptr(labels), Bq, K, L.ptr(loss),
+                                 L.ptr(scores), L.ptr(order), stream), self.h, "rr_head")
+        return dict(loss=loss, scores=scores, order=order)
+
+    # ---- debugging / profiling ------------------------------------------------------------------
+    def set_debug(self, on: bool):
+        L.check(self.lib.rr_set_debug(self.h, int(on)), self.h)
+
+    def debug_read(self, name: str, numel: int) -> torch.Tensor:
+        out = torch.empty(numel, dtype=torch.float32)
+        n = self.lib.rr_debug_read(self.h, name.encode(), out.data_ptr(), numel)
+        if n < 0:
+            L.check(int(n), self.h, "rr_debug_read")
+        return out[:n]
+
+    def set_profiling(self, on: bool):
+        L.check(self.lib.rr_set_profiling(self.h, int(on)), self.h)
+
+    def get_profile(self, reset: bool = True) -> Dict[str, dict]:
+        p = L.RRProfile()
+        L.check(self.lib.rr_get_profile(self.h, C.byref(p), int(reset)), self.h, "rr_get_profile")
+        return {k: dict(ms=p.ms[i], launches=p.launches[i], flops=p.flops[i], bytes=p.bytes[i])
+                for i, k in enumerate(L.KERNEL_CLASSES)}
+
+    def workspace_bytes(self, n_pairs: int, S: int) -> int:
+        return int(self.lib.rr_workspace_bytes(self.h, n_pairs, S))
+
+
+class _FrozenStub(torch.nn.Module):
+    """Placeholder for `context_vision_encoder`: the executor only iterates its `named_parameters()` to
+    freeze them (Reranker_base_executor.py:204-207).  The CLIP ViT is upstream of this path."""
+
+
+class FullContextRerankModel(torch.nn.Module):
+    """Drop-in for the reference's `FullContextRerankModel` (rerank_model.py:515-591), inference only.
+
+    `config` is the reference `reranker_config` (EasyDict/dict).  Extra, optional keys:
+      `arch`            – dict overriding the FLMR/BERT architecture defaults (tests use tiny shapes)
+      `tokenizer`       – any HF-style tokenizer (encode/decode/batch_encode_plus); required only for the
+                          text call signature (no vocab file exists in the build environment)
+      `image_feature_fn`– callable pixel_values[Bq,3,224,224] -> (cls [Bq,Vh], patches [Bq,np,Vh]); required only
+                          when `query_pixel_values` is passed (the CLIP ViT is upstream of the path)
+      `text_only`       – build without the vision weights (`text_only` module of the reference configs)
+    """
+
+    def __init__(self, config, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None):
+        super().__init__()
+        self.config = config
+        arch = make_arch(config)
+        if _get(config, "text_only", False):
+            arch["has_vision"] = 0
+        self.engine = RerankEngine(arch, device)
+        self.max_query_length = _get(config, "max_query_length", 32)
+        self.max_decoder_source_length = _get(config, "max_decoder_source_length", 512)
+        self.max_context_length = self.max_decoder_source_length - self.max_query_length - 4   # HEAD_TOKEN_LEEWAY
+        self.query_tokenizer = _get(config, "tokenizer", None)
+        self.image_feature_fn = _get(config, "image_feature_fn", None)
+        self.context_vision_encoder = _FrozenStub()
+        if state_dict is not None:
+            self.engine.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict: bool = False, prefix: str = ""):  # type: ignore[override]
+        return self.engine.load_state_dict(state_dict, strict=strict, prefix=prefix)
+
+    # tensor fast path (synthetic benchmarks, pre-tokenised callers)
+    def forward_ids(self, input_ids, attention_mask, token_type_ids, num_negative_examples: int,
+                    image_cls=None, image_patches=None, labels: Optional[List[float]] = None, **kw) -> RerankOutput:
+        K = num_negative_examples + 1
+        N = input_ids.shape[0]
+        assert N % K == 0, "expanded batch size must be batch_size * (num_negative_examples + 1)"
+        Bq = N // K
+        arch = self.engine.arch
+        if labels is not None:
+            assert isinstance(labels, list), "Labels must be a list"                       # utils.py:232
+            if arch["loss_fn"] == "negative_sampling":
+                raise AssertionError("Labels should not be provided for negative sampling loss function")
+            assert len(labels) == N                                                        # rerank_model.py:528-529
+            labels_t = torch.tensor(labels, dtype=torch.float32, device=self.engine.device)
+        else:
+            labels_t = None
+        r = self.engine.forward_ids(input_ids, attention_mask, token_type_ids, Bq, K, image_cls, image_patches,
+                                    labels_t, **kw)
+        logits = r["logits"]
+        logits = logits.view(Bq, K) if arch["loss_fn"] == "negative_sampling" else logits.view(N, 1)
+        out = RerankOutput(loss=r["loss"], logits=logits)
+        for k in ("scores", "order", "logits2"):
+            if r.get(k) is not None:
+                out[k] = r[k]
+        return out
+
+    def forward(self, query_text_sequences, query_pixel_values, context_text_sequences, num_negative_examples,
+                labels=None) -> RerankOutput:
+        text_only = query_pixel_values is None
+        batch_size = len(query_text_sequences)
+        expanded = batch_size * (num_negative_examples + 1)
+        assert expanded == len(context_text_sequences)                                     # rerank_model.py:527
+        if labels:
+            assert len(labels) == expanded
+        if self.query_tokenizer is None:
+            raise RuntimeError("text call signature needs config.tokenizer (an HF-style BERT tokenizer)")
+        from .tokenize import prepare_full_context_inputs
+        enc = prepare_full_context_inputs(query_text_sequences, context_text_sequences, self.query_tokenizer,
+                                          self.max_query_length, self.max_context_length,
+                                          self.max_decoder_source_length, num_negative_examples + 1)
+        dev = self.engine.device
+        cls = patches = None
+        if not text_only:
+            if self.image_feature_fn is None:
+                raise NotImplementedError("query_pixel_values given but config.image_feature_fn (CLIP ViT) is not set")
+            cls, patches = self.image_feature_fn(query_pixel_values)
+        return self.forward_ids(enc["input_ids"].to(dev), enc["attention_mask"].to(dev),
+                                enc["token_type_ids"].to(dev), num_negative_examples, cls, patches,
+                                labels if labels else None)

@@ -1,0 +1,178 @@
+"""Golden-vector generator (runs ONLY in the build container; never on the GPU box).
+
+The reference's own modules cannot be imported here (missing `pytorch_lightning`,
+`easydict`, `peft`, `faiss`, `colbert`, `tkinter`; pinned `transformers==4.38.2` absent —
+SURVEY.md §8c: ordinary ImportErrors, nothing permission-denied) and the reference
+ships no golden vectors for this path.  The arithmetic of the path lives in stock
+HuggingFace `BertModel` / `BertEncoder`; this script therefore assembles those stock
+modules (installed transformers, eager attention) in the order the reference composes
+them (`/root/reference/src/models/rerank/rerank_model.py:333-479,523-591`,
+`utils.py:73-108,228-254`, `modeling_flmr.py:603-664,1616-1688`), loads the seeded
+synthetic weights by the reference's state_dict key names, runs fp32 on CPU and
+writes inputs + expected outputs to `tests/golden/*.npz`.
+
+It also cross-checks `oracle/rerank_oracle.py` against the HF assembly (max-abs diff
+printed and stored) — that is the oracle's pin.
+
+Usage:  python tests/golden/make_golden.py [--which tiny,tiny_mm,c1,...]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import rerank_oracle as O  # noqa: E402
+
+from transformers import BertConfig, BertModel  # noqa: E402
+from transformers.models.bert.modeling_bert import BertEncoder  # noqa: E402
+
+
+def hf_cfg(hidden, layers, heads, inter, max_pos, vocab, eps, **kw):
+    c = BertConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers,
+                   num_attention_heads=heads, intermediate_size=inter,
+                   max_position_embeddings=max_pos, type_vocab_size=2, hidden_act="gelu",
+                   hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                   layer_norm_eps=eps, **kw)
+    c._attn_implementation = "eager"
+    return c
+
+
+def load_prefixed(module, w, prefix):
+    sd = module.state_dict()
+    new = {}
+    for k in sd:
+        full = prefix + k
+        if full in w:
+            new[k] = w[full].clone()
+        else:
+            new[k] = sd[k]          # unused tensors (pooler, CE word embeddings) keep their init
+    module.load_state_dict(new)
+    module.eval()
+
+
+class HFAssembly:
+    """Stock-HF restatement of the module graph the reference builds."""
+
+    def __init__(self, cfg: O.OracleConfig, w, vision: bool):
+        self.cfg, self.w, self.vision = cfg, w, vision
+        self.text = BertModel(hf_cfg(cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate, cfg.max_pos,
+                                     cfg.vocab_size, cfg.ln_eps), add_pooling_layer=True)
+        load_prefixed(self.text, w, "context_text_encoder.bert_model.")
+        self.ce = BertModel(hf_cfg(cfg.ce_hidden, cfg.ce_layers, cfg.ce_heads, cfg.ce_intermediate,
+                                   cfg.ce_max_pos, cfg.vocab_size, cfg.ln_eps), add_pooling_layer=True)
+        load_prefixed(self.ce, w, "reranker.bert_model.")
+        if vision:
+            mc = hf_cfg(cfg.hidden, cfg.map_layers, cfg.heads, cfg.intermediate, cfg.max_pos,
+                        cfg.vocab_size, cfg.ln_eps, is_decoder=True, add_cross_attention=True)
+            self.mapnet = BertEncoder(mc)
+            load_prefixed(self.mapnet, w, "transformer_mapping_network.")
+
+    def lin(self, x, name):
+        b = self.w.get(name + ".bias")
+        return torch.nn.functional.linear(x, self.w[name + ".weight"], b)
+
+    @torch.no_grad()
+    def forward(self, ids, am, tt, Bq, K, img_cls=None, img_patches=None, labels=None):
+        cfg = self.cfg
+        N = Bq * K
+        hs = self.text(input_ids=ids, attention_mask=am, token_type_ids=tt).last_hidden_state
+        text = self.lin(hs, "context_text_encoder_linear")
+        mask = (ids != 0).float()
+        text = text * mask.unsqueeze(2)
+        Q = text
+        if self.vision:
+            c = img_cls.repeat_interleave(K, 0)
+            pt = img_patches.repeat_interleave(K, 0)
+            x = self.lin(torch.tanh(self.lin(c, "context_vision_projection.model.0")),
+                         "context_vision_projection.model.2").view(N, -1, cfg.li_dim)
+            t = self.lin(pt, "transformer_mapping_input_linear")
+            enc = hs[:, : cfg.cross_attn_len]
+            enc_mask = torch.zeros(N, 1, 1, enc.shape[1])      # inverted all-ones mask
+            t = self.mapnet(t, encoder_hidden_states=enc, encoder_attention_mask=enc_mask).last_hidden_state
+            t = self.lin(t, "transformer_mapping_output_linear")
+            Q = torch.cat([text, x, t], dim=1)
+        Q = torch.nn.functional.normalize(Q, p=2, dim=2)
+        x = self.lin(Q, "cross_encoder_input_mapping")
+        P = x.shape[1] - mask.shape[1]
+        m = torch.cat([mask, torch.ones(N, P)], 1) if P else mask
+        h = self.ce(inputs_embeds=x, attention_mask=m).last_hidden_state
+        cls = h[:, 0]
+        l1, l2 = self.lin(cls, "reranker.classifier1"), self.lin(cls, "reranker.classifier2")
+        logits, lab = O.prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)
+        loss = O.loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)
+        if cfg.loss_fn == "2H_BCE":
+            logits = logits[:, 1].unsqueeze(1)
+        return loss, logits, hs, Q
+
+
+CASES = {
+    # name: (cfg kwargs, Bq, K, S, vision, regime, loss)
+    "tiny": (dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_pos=64,
+                  ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=1, ce_max_pos=128,
+                  li_dim=64), 2, 3, 64, False, "realistic", "BCE"),
+    "tiny_mm": (dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_pos=64,
+                     ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128,
+                     li_dim=64, vision_hidden=128, prefix_len=4, n_patches=9, cross_attn_len=32),
+                2, 3, 64, True, "realistic", "negative_sampling"),
+    "tiny_2h": (dict(vocab_size=2000, hidden=128, layers=1, heads=2, intermediate=512, max_pos=64,
+                     ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=1, ce_max_pos=128,
+                     li_dim=64, pos_weight=3.0), 2, 4, 64, False, "realistic", "2H_BCE"),
+    "c1": (dict(), 2, 5, 128, False, "realistic", "BCE"),                 # BASELINE configs[0]
+    "c2": (dict(), 1, 20, 256, False, "realistic", "BCE"),                # BASELINE configs[1]
+    "c3s": (dict(), 1, 4, 512, True, "realistic", "negative_sampling"),   # configs[2] shape, K cut to 4
+}
+
+
+def run_case(name, outdir):
+    kw, Bq, K, S, vision, regime, loss = CASES[name]
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = loss
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=2022, regime=regime)
+    img = O.make_image_feats(cfg, Bq) if vision else (None, None)
+    labels = None
+    if loss != "negative_sampling":
+        rng = np.random.Generator(np.random.PCG64(5))
+        labels = [float(x) for x in (rng.random(Bq * K) < 0.3)]
+    hf = HFAssembly(cfg, w, vision)
+    loss_hf, logits_hf, hs_hf, Q_hf = hf.forward(ids, am, tt, Bq, K, img[0], img[1], labels)
+    out = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, img[0], img[1], labels, want_taps=True)
+    d_logit = (out.logits - logits_hf).abs().max().item()
+    d_loss = (out.loss - loss_hf).abs().item()
+    d_hs = (out.taps[f"text_layer_{cfg.layers - 1}"] - hs_hf).abs().max().item()
+    d_q = (out.taps["late_interaction"] - Q_hf).abs().max().item()
+    print(f"[{name}] oracle-vs-HF: logits {d_logit:.3e} loss {d_loss:.3e} text_hidden {d_hs:.3e} LI {d_q:.3e}")
+    # weight checksums guard against RNG drift between torch builds
+    wsum = np.array([float(w[k].double().sum()) for k in sorted(w)][:64])
+    order = [O.rank_descending_stable(r) for r in
+             logits_hf.view(Bq, -1).tolist()] if logits_hf.numel() == Bq * K else []
+    np.savez_compressed(
+        os.path.join(outdir, f"{name}.npz"),
+        cfg_json=np.array(repr(kw)), Bq=Bq, K=K, S=S, vision=vision, loss_fn=np.array(loss),
+        pos_weight=np.array(cfg.pos_weight if cfg.pos_weight is not None else np.nan),
+        input_ids=ids.numpy(), attention_mask=am.numpy(), token_type_ids=tt.numpy(),
+        image_cls=(img[0].numpy() if vision else np.zeros(0, np.float32)),
+        image_patches=(img[1].numpy() if vision else np.zeros(0, np.float32)),
+        labels=np.array(labels if labels is not None else [], dtype=np.float32),
+        logits=logits_hf.numpy(), loss=np.array(loss_hf.item(), dtype=np.float32),
+        order=np.array(order, dtype=np.int32),
+        text_hidden_cls=hs_hf[:, 0].numpy(),                  # CLS row of the 12-layer encoder
+        text_hidden_absmean=np.array(hs_hf.abs().mean().item()),
+        late_interaction_row0=Q_hf[:, 0].numpy(), weight_sums=wsum,
+        oracle_vs_hf=np.array([d_logit, d_loss, d_hs, d_q]),
+    )
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default=",".join(CASES))
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for nm in a.which.split(","):
+        run_case(nm, os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,180 @@
+"""GPU parity of the whole hot path through the C ABI against (a) the committed golden logits from the
+stock-HF assembly (fp32), (b) the CPU oracle run with the device's bf16 rounding points.
+
+Tolerances (DESIGN.md "Numerics"): bf16 operand rounding alone moves bert-base logits by ~2e-3 against an
+fp32 forward (the reference's own bf16-mixed forward moves by 1.3e-3..6e-3; tools/precision_study.py), so
+  * vs the oracle WITH the same rounding points: |dlogit| <= 1e-3   (north_star: "within 1e-3 bf16")
+  * vs the fp32 goldens:                          |dlogit| <= 8e-3   (bounded by bf16 itself, not by the kernels)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, arch_from_cfg, golden_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_SAME_ROUNDING = 1e-3
+TOL_VS_FP32 = 8e-3
+
+
+def _engine(cfg, vision, w):
+    import rmr_amd
+    eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, vision))
+    eng.load_state_dict(w)
+    return eng
+
+
+def _run(name, want_taps=False):
+    g = load_golden(name)
+    cfg, vision = g["cfg"], g["vision"]
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    eng = _engine(cfg, vision, w)
+    ids, am, tt, img = golden_inputs(g)
+    lab = torch.tensor(g["labels_list"]).cuda() if g["labels_list"] is not None else None
+    eng.set_debug(True)
+    r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"],
+                        img[0].cuda() if vision else None, img[1].cuda() if vision else None, lab,
+                        want_scores=True, want_order=True)
+    torch.cuda.synchronize()
+    return g, w, eng, r
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_mm", "tiny_2h", "c1", "c2", "c3s"])
+def test_forward_matches_golden_and_oracle(name):
+    g, w, eng, r = _run(name)
+    cfg, Bq, K = g["cfg"], g["Bq"], g["K"]
+    logits = r["logits"].cpu()
+    assert torch.isfinite(logits).all()
+    gold = torch.from_numpy(g["logits"]).reshape(-1)
+    d32 = (logits - gold).abs().max().item()
+    ids, am, tt, img = golden_inputs(g)
+    torch.set_num_threads(8)
+    with torch.no_grad(), O.device_rounding() as mm:
+        emu = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, img[0], img[1], g["labels_list"], mm=mm,
+                                     want_taps=True)
+    demu = (logits - emu.logits.reshape(-1)).abs().max().item()
+    # intermediate taps localise a failure: text encoder output and the normalised late-interaction rows
+    S, H = g["S"], cfg.hidden
+    th = eng.debug_read("text_hidden", Bq * K * S * H).view(Bq * K, S, H)
+    dth = (th - emu.taps[f"text_layer_{cfg.layers - 1}"]).abs().max().item()
+    T = emu.taps["late_interaction"].shape[1]
+    li = eng.debug_read("late_interaction", Bq * K * T * cfg.li_dim).view(Bq * K, T, cfg.li_dim)
+    dli = (li - emu.taps["late_interaction"]).abs().max().item()
+    print(f"[{name}] |dlogit| vs same-rounding oracle {demu:.2e}, vs fp32 golden {d32:.2e}; "
+          f"text_hidden {dth:.2e}; late_interaction {dli:.2e}")
+    assert dth < 3e-2 and dli < 1e-2
+    assert demu <= TOL_SAME_ROUNDING
+    assert d32 <= TOL_VS_FP32
+    # loss follows the logits
+    assert abs(r["loss"].item() - emu.loss.item()) < 2e-3
+    assert abs(r["loss"].item() - float(g["loss"])) < 1e-2
+    # device order == stable descending sort of the device logits (bit-exact integer work)
+    want = [O.rank_descending_stable(row) for row in logits.view(Bq, K).tolist()]
+    assert r["order"].cpu().tolist() == want
+    # scores
+    if cfg.loss_fn == "BCE":
+        assert torch.allclose(r["scores"].cpu(), torch.sigmoid(logits), atol=1e-6)
+    elif cfg.loss_fn == "negative_sampling":
+        assert torch.allclose(r["scores"].cpu().view(Bq, K), torch.softmax(logits.view(Bq, K), -1), atol=1e-6)
+
+
+def test_top5_sets_match_oracle_when_gaps_allow():
+    """Recall@5 parity: identical top-5 id sets wherever the oracle's gap between rank 5 and 6 exceeds the
+    bf16 tolerance (random-weight logits are nearly tied, so the gap condition is part of the statement)."""
+    g, w, eng, r = _run("c2")
+    Bq, K = g["Bq"], g["K"]
+    gold = torch.from_numpy(g["logits"]).view(Bq, K)
+    dev = r["logits"].cpu().view(Bq, K)
+    for qi in range(Bq):
+        o = O.rank_descending_stable(gold[qi].tolist())
+        gap = gold[qi, o[4]] - gold[qi, o[5]]
+        if gap > 2 * TOL_VS_FP32:
+            assert set(o[:5]) == set(r["order"][qi, :5].cpu().tolist())
+        # Spearman-style sanity: device ranking correlates strongly with the fp32 ranking
+        rk_g = torch.tensor(o).argsort().float()
+        rk_d = r["order"][qi].cpu().long().argsort().float()
+        rho = torch.corrcoef(torch.stack([rk_g, rk_d]))[0, 1].item()
+        assert rho > 0.9
+
+
+def test_pair_slices_compose_to_full_forward():
+    """Multi-GPU contract on one GPU: two rr_forward calls on disjoint pair slices + rr_head == one full call."""
+    g, w, eng, r = _run("tiny_mm")
+    Bq, K = g["Bq"], g["K"]
+    N = Bq * K
+    ids, am, tt, img = golden_inputs(g)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K, img[0].cuda(), img[1].cuda(), None)
+    cut = 2                                                  # splits query 0's candidates across "ranks"
+    a = eng.forward_ids(*args, pair_range=(0, cut), want_loss=False)["logits"][:cut]
+    b = eng.forward_ids(*args, pair_range=(cut, N), want_loss=False)["logits"][cut:]
+    full = torch.cat([a, b])
+    torch.cuda.synchronize()
+    assert torch.equal(full, r["logits"])                    # same kernels, same inputs: bit-identical
+    h = eng.head(full, None, None, Bq, K, want_scores=True)
+    torch.cuda.synchronize()
+    assert torch.equal(h["order"], r["order"])
+    assert h["loss"].item() == r["loss"].item()
+
+
+def test_repeatable_and_workspace_reuse():
+    g, w, eng, r = _run("tiny")
+    ids, am, tt, _ = golden_inputs(g)
+    r2 = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], labels=torch.tensor(g["labels_list"]).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(r2["logits"], r["logits"])
+    assert eng.workspace_bytes(g["Bq"] * g["K"], g["S"]) > 0
+
+
+def test_error_behaviour_mirrors_reference():
+    import rmr_amd
+    g = load_golden("tiny")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, 0, False)
+    arch = arch_from_cfg(cfg, False)
+    eng = rmr_amd.RerankEngine(arch)
+    ids, am, tt, _ = golden_inputs(g)
+    with pytest.raises(ValueError):                           # forward before weights
+        eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"])
+    missing = dict(w)
+    missing.pop("reranker.classifier1.weight")
+    with pytest.raises(KeyError):
+        rmr_amd.RerankEngine(arch).load_state_dict(missing)
+    bad = dict(w)
+    bad["reranker.classifier1.weight"] = torch.zeros(2, cfg.ce_hidden)
+    with pytest.raises(AssertionError):
+        rmr_amd.RerankEngine(arch).load_state_dict(bad)
+    eng.load_state_dict(dict(w, **{"some.unrelated.key": torch.zeros(3)}))    # strict=False semantics
+    with pytest.raises(AssertionError):                       # N != Bq*K  (rerank_model.py:527)
+        eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"] + 1, g["K"])
+    long_ids = torch.ones(2, cfg.max_pos + 8, dtype=torch.int64).cuda()
+    with pytest.raises(AssertionError):                       # S > max_position_embeddings
+        eng.forward_ids(long_ids, long_ids, long_ids * 0, 1, 2)
+    with pytest.raises(NotImplementedError):                  # image features into a text_only build
+        eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], torch.zeros(g["Bq"], 128).cuda(),
+                        torch.zeros(g["Bq"], 9, 128).cuda())
+    ns = rmr_amd.RerankEngine(dict(arch, loss_fn="negative_sampling"))
+    ns.load_state_dict(w)
+    with pytest.raises(ValueError):                           # labels with negative_sampling (utils.py:233)
+        ns.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], labels=torch.zeros(g["Bq"] * g["K"]).cuda())
+    with pytest.raises(ValueError):
+        rmr_amd.RerankEngine(dict(arch, loss_fn="hinge"))
+    with pytest.raises(NotImplementedError):
+        rmr_amd.RerankEngine(dict(arch, hidden=96, heads=2))
+
+
+def test_module_interface_returns_loss_and_logits():
+    import rmr_amd
+    g = load_golden("tiny_mm")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, 0, True)
+    conf = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn=cfg.loss_fn, pos_weight=None, max_query_length=8, max_decoder_source_length=g["S"],
+                arch=arch_from_cfg(cfg, True))
+    m = rmr_amd.FullContextRerankModel(conf, state_dict=w)
+    ids, am, tt, img = golden_inputs(g)
+    out = m.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["K"] - 1, img[0].cuda(), img[1].cuda())
+    assert out.logits.shape == (g["Bq"], g["K"]) and out.loss.dim() == 0      # listwise: [Bq, K]
+    assert len(out.logits.squeeze().tolist()) == g["Bq"]                        # caller's .squeeze().tolist()
+    assert abs(out.loss.detach().cpu().item() - float(g["loss"])) < 1e-2
+    assert list(m.context_vision_encoder.named_parameters()) == []

@@ -1,0 +1,202 @@
+"""GPU parity of the stand-alone HIP operators, called through the C ABI (rr_op_*), against plain fp32
+torch references on the same (bf16-rounded) inputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import rmr_amd
+    from rmr_amd import _lib
+    return _lib.load()       # raises if librerank_mi355.so is missing: no fallback
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bits(t):
+    return t.view(torch.int16)
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 768, 768), (200, 2304, 768), (77, 128, 768),
+                                   (1, 2048, 768), (333, 768, 3072), (130, 64, 128), (512, 3072, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(lib, M, N, K, epi):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if epi == 2 else torch.bfloat16)
+    rc = lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, epi, out.data_ptr(), _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + b
+    ref = {0: ref, 1: _gelu(ref), 2: ref, 3: torch.tanh(ref)}[epi]
+    got = out.float()
+    assert torch.isfinite(got).all()
+    tol = 2e-4 if epi == 2 else 1.2e-2     # fp32 out: accumulation-order noise; bf16 out: half-ulp of |x| <~ 3
+    err = (got - ref).abs()
+    assert (err <= tol * (1 + ref.abs())).all(), f"max err {err.max().item()}"
+
+
+def test_gemm_no_bias_and_resid(lib):
+    M, N, K = 300, 768, 768
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda()
+    out = torch.empty(M, N, device="cuda")
+    assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), 0, M, N, K, 2, out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(out, A.float() @ W.float().t(), atol=3e-4, rtol=1e-4)
+    assert lib.rr_op_gemm_resid_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), M, N, K,
+                                    out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(out, A.float() @ W.float().t() + b + R, atol=3e-4, rtol=1e-4)
+
+
+def test_gemm_asymmetric_identity(lib):
+    """A = I against an asymmetric W catches a transposed C-write (cdna guide §3)."""
+    K = 128
+    A = torch.eye(K).bfloat16().cuda()
+    W = (torch.arange(K * K, dtype=torch.float32).view(K, K) % 251 - 125).bfloat16().cuda()   # exact in bf16
+    out = torch.empty(K, K, device="cuda")
+    assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), 0, K, K, K, 2, out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, W.float().t())
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    A = torch.zeros(8, 96).bfloat16().cuda()
+    out = torch.zeros(8, 8, device="cuda")
+    assert lib.rr_op_gemm_bf16(A.data_ptr(), A.data_ptr(), 0, 8, 8, 96, 2, out.data_ptr(), _stream()) == -2   # K % 64
+
+
+def _attn_ref(q, k, v, bias, heads, qdiv=1):
+    B, Tk = k.shape[0], k.shape[1]
+    Tq = q.shape[1]
+    qq = q.float().repeat_interleave(qdiv, 0)[:B]
+    qh = qq.view(B, Tq, heads, 64).transpose(1, 2)
+    kh = k.float().view(B, Tk, heads, 64).transpose(1, 2)
+    vh = v.float().view(B, Tk, heads, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)                     # q is pre-scaled
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, heads * 64)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,masked", [(2, 2, 64, 64, False), (3, 12, 128, 128, True), (2, 12, 512, 512, True),
+                                                   (2, 2, 593, 593, True), (4, 12, 49, 49, False), (6, 12, 49, 32, False),
+                                                   (1, 1, 1, 1, False), (2, 3, 70, 130, True)])
+def test_attention(lib, B, heads, Tq, Tk, masked):
+    g = torch.Generator().manual_seed(B * 100 + Tq + Tk)
+    H = heads * 64
+    q = (torch.randn(B, Tq, H, generator=g) * 0.5).bfloat16().cuda()
+    k = torch.randn(B, Tk, H, generator=g).bfloat16().cuda()
+    v = torch.randn(B, Tk, H, generator=g).bfloat16().cuda()
+    bias = None
+    if masked:
+        keep = torch.rand(B, Tk, generator=g) > 0.3
+        keep[:, 0] = True
+        if Tk > 40:
+            keep[0, 5:40] = False                       # a long masked run inside a tile
+        bias = torch.where(keep, 0.0, -1e30).float().cuda()
+    out = torch.full((B, Tq, H), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), H, H, bias.data_ptr() if masked else 0,
+                                  B, heads, Tq, Tk, 1, out.data_ptr(), H, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, bias, heads)
+    got = out.float()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 2e-2       # bf16 P and bf16 output on |O| <~ 1
+
+
+def test_attention_fused_qkv_layout_and_query_broadcast(lib):
+    """strided q/k/v inside one [rows, 3H] buffer (as the QKV GEMM writes it) and per-query Q shared by K pairs."""
+    B, heads, T = 3, 2, 96
+    H = heads * 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * T, 3 * H, generator=g).bfloat16().cuda()
+    out = torch.empty(B, T, H, dtype=torch.bfloat16, device="cuda")
+    base = qkv.data_ptr()
+    rc = lib.rr_op_attention_bf16(base, base + 2 * H, base + 4 * H, 3 * H, 3 * H, 0, B, heads, T, T, 1,
+                                  out.data_ptr(), H, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    x = qkv.view(B, T, 3 * H)
+    ref = _attn_ref(x[..., :H], x[..., H:2 * H], x[..., 2 * H:], None, heads)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    # q_batch_div: 2 queries, each shared by 3 pairs
+    q = torch.randn(2, 49, H, generator=g).bfloat16().cuda()
+    k = torch.randn(6, 32, H, generator=g).bfloat16().cuda()
+    v = torch.randn(6, 32, H, generator=g).bfloat16().cuda()
+    out = torch.empty(6, 49, H, dtype=torch.bfloat16, device="cuda")
+    assert lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), H, H, 0, 6, heads, 49, 32, 3,
+                                    out.data_ptr(), H, _stream()) == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, None, heads, qdiv=3)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+
+
+def test_attention_all_masked_row_is_uniform(lib):
+    B, heads, T = 2, 1, 100
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, T, 64, generator=g).bfloat16().cuda()
+    k = torch.randn(B, T, 64, generator=g).bfloat16().cuda()
+    v = torch.randn(B, T, 64, generator=g).bfloat16().cuda()
+    bias = torch.zeros(B, T)
+    bias[1] = -1e30                                     # pair 1: no valid key at all
+    bias = bias.cuda()
+    out = torch.empty(B, T, 64, dtype=torch.bfloat16, device="cuda")
+    assert lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), 64, 64, bias.data_ptr(), B, heads, T, T,
+                                    1, out.data_ptr(), 64, _stream()) == 0
+    torch.cuda.synchronize()
+    want = v[1].float().mean(0, keepdim=True).expand(T, 64)
+    assert (out[1].float() - want).abs().max().item() < 1e-2
+    ref0 = _attn_ref(q[:1], k[:1], v[:1], None, 1)
+    assert (out[0].float() - ref0[0]).abs().max().item() < 2e-2
+
+
+def test_attention_online_softmax_rescale(lib):
+    """Force the running max to jump in a late tile (rule 26: rare data-dependent branch needs its own test)."""
+    B, heads, T = 1, 1, 256
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(B, T, 64, generator=g) * 0.3
+    k = torch.randn(B, T, 64, generator=g) * 0.3
+    k[0, 200] = q[0, 17] * 40.0                         # key 200 (tile 3) spikes against query 17
+    k[0, 70] = q[0, 90] * 25.0
+    v = torch.randn(B, T, 64, generator=g)
+    q, k, v = q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda()
+    out = torch.empty(B, T, 64, dtype=torch.bfloat16, device="cuda")
+    assert lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), 64, 64, 0, B, heads, T, T, 1,
+                                    out.data_ptr(), 64, _stream()) == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, None, 1)
+    assert (out.float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (5, 64)])
+def test_layernorm(lib, rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 3 + 0.5).cuda()
+    gamma = (1 + 0.1 * torch.randn(cols, generator=g)).cuda()
+    beta = (0.1 * torch.randn(cols, generator=g)).cuda()
+    o32 = torch.empty_like(x)
+    o16 = torch.empty(rows, cols, dtype=torch.bfloat16, device="cuda")
+    assert lib.rr_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-12, rows, cols, o32.data_ptr(),
+                               o16.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (cols,), gamma, beta, 1e-12)
+    assert torch.allclose(o32, ref, atol=2e-6, rtol=1e-5)
+    assert torch.equal(o16, o32.bfloat16())

@@ -1,0 +1,100 @@
+"""CPU: the oracle against the committed golden vectors (generated from the stock-HF assembly by
+tests/golden/make_golden.py), plus the head/rank/metric restatements against hand-computed cases."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import O, golden_inputs, load_golden
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_mm", "tiny_2h", "c1"])
+def test_oracle_matches_golden(name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=g["vision"])
+    wsum = np.array([float(w[k].double().sum()) for k in sorted(w)][:64])
+    np.testing.assert_allclose(wsum, g["weight_sums"], rtol=1e-6, atol=1e-6,
+                               err_msg="seeded weight generator drifted from the one the goldens were made with")
+    ids, am, tt, img = golden_inputs(g)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = O.full_context_forward(cfg, w, ids, am, tt, g["Bq"], g["K"], img[0], img[1], g["labels_list"],
+                                     want_taps=True)
+    # fp32 CPU restatement vs fp32 HF: only accumulation-order noise
+    np.testing.assert_allclose(out.logits.numpy(), g["logits"], atol=2e-5, rtol=0)
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-5
+    hs = out.taps[f"text_layer_{cfg.layers - 1}"][:, 0].numpy()
+    np.testing.assert_allclose(hs, g["text_hidden_cls"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out.taps["late_interaction"][:, 0].numpy(), g["late_interaction_row0"], atol=5e-6)
+    if g["order"].size:
+        got = [O.rank_descending_stable(r) for r in out.logits.view(g["Bq"], -1).tolist()]
+        assert got == g["order"].tolist()
+
+
+def test_generator_pin_recorded():
+    for name in ["tiny", "tiny_mm", "tiny_2h", "c1", "c2", "c3s"]:
+        d = load_golden(name)["oracle_vs_hf"]
+        assert d[0] < 1e-5 and d[1] < 1e-5, f"{name}: oracle was not pinned to HF when the golden was generated"
+
+
+def test_rank_is_descending_and_stable():
+    s = [0.5, 0.9, 0.5, -1.0, 0.9, 0.5]
+    assert O.rank_descending_stable(s) == [1, 4, 0, 2, 5, 3]       # ties keep retrieval order
+    docs = list(zip("abcdef", s))
+    assert [d[0] for d in sorted(docs, key=lambda x: x[1], reverse=True)] == list("beacfd")
+
+
+def test_recall_at_k_cases():
+    Ks = [1, 5, 6]
+    ranked = [[10, 11, 12, 13, 14, 15, 16],      # positive at rank 1
+              [20, 21, 22, 23, 24, 25, 26],      # positive at rank 5
+              [30, 31, 32, 33, 34, 35, 36],      # positive at rank 6
+              [40, 41, 42, 43, 44, 45, 46]]      # none
+    pos = [[10], [24, 999], [35], [7]]
+    r = O.recall_precision_at_k(ranked, pos, Ks)
+    assert r["recall"] == [1 / 4, 2 / 4, 3 / 4]
+    assert r["precision"] == pytest.approx([1 / 4, (1 / 5 + 1 / 5) / 4, (1 / 6 + 1 / 6 + 1 / 6) / 4])
+
+
+def test_losses_match_torch_modules():
+    torch.manual_seed(1)
+    l1, l2 = torch.randn(6, 1), torch.randn(6, 1)
+    # BCE default labels: first of each K positive (utils.py:239-243)
+    lg, lab = O.prepare_logits_labels("BCE", l1, l2, 2, 2, None)
+    assert lab.view(-1).tolist() == [1, 0, 0, 1, 0, 0]
+    want = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([3.0]))(l1, lab)
+    assert torch.allclose(O.loss_value("BCE", 3.0, lg, lab), want)
+    # listwise: logits.view(Bq, K), target 0
+    lg, lab = O.prepare_logits_labels("negative_sampling", l1, l2, 2, 2, None)
+    assert lg.shape == (2, 3) and lab.tolist() == [0, 0]
+    assert torch.allclose(O.loss_value("negative_sampling", None, lg, lab), F.cross_entropy(l1.view(2, 3), lab))
+    with pytest.raises(AssertionError):
+        O.prepare_logits_labels("negative_sampling", l1, l2, 2, 2, [0.0] * 6)
+    # two heads
+    lg, lab = O.prepare_logits_labels("2H_BCE", l1, l2, 2, 2, [0., 1., 0., 0., 0., 1.])
+    assert lg.shape == (6, 2) and lab.dtype == torch.long
+    want = F.cross_entropy(torch.cat([l1, l2], 1), lab, weight=torch.tensor([1.0, 2.0]))
+    assert torch.allclose(O.loss_value("2H_BCE", 2.0, lg, lab), want)
+
+
+def test_all_masked_row_is_uniform():
+    """finfo.min masking: a query row whose keys are all masked attends uniformly (softmax of a constant row)."""
+    q = torch.randn(1, 3, 64)
+    k = torch.randn(1, 5, 64)
+    v = torch.randn(1, 5, 64)
+    m = O.extended_mask(torch.zeros(1, 5))
+    out = O.multi_head_attention(q, k, v, 1, m)
+    assert torch.allclose(out, v.mean(1, keepdim=True).expand(1, 3, 64), atol=1e-6)
+    with O.device_rounding():
+        out2 = O._MHA[-1](q, k, v, 1, m)
+    assert torch.allclose(out2, O._bf(v).mean(1, keepdim=True).expand(1, 3, 64), atol=1e-6)
+
+
+def test_flops_per_pair_matches_survey():
+    cfg = O.OracleConfig()
+    assert O.flops_per_pair(cfg, 512, False) / 1e9 == pytest.approx(104.9, abs=0.3)   # SURVEY §8d c3 text-only
+    assert O.flops_per_pair(cfg, 128, False) / 1e9 == pytest.approx(24.3, abs=0.2)    # c1
+    assert O.flops_per_pair(cfg, 512, True) / 1e9 == pytest.approx(107.3, abs=0.5)    # c3
