@@ -49,14 +49,26 @@ def flops_per_pair(a, S, vision):
     return f
 
 
+def host_cores():
+    """CPU threads this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(arch, sd, K, S, vision, target_pairs):
     """The oracle (fp32 torch restatement of the reference forward) timed on this box's host cores, on a
     bounded sample of the same workload.  Reported beside the GPU number; never the thing shipped."""
     from oracle import rerank_oracle as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(**{k: arch[k] for k in (
         "vocab_size", "hidden", "layers", "heads", "intermediate", "max_pos", "type_vocab", "ln_eps", "li_dim",

@@ -184,6 +184,13 @@ int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias
 int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
                          const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out,
                          int out_stride, void* hip_stream);
+/* Tuning hooks (tools/bench_gemm.py). rr_set_gemm_variant forces a tile configuration: 0..3 = "simple" loop
+ * {128x128x2st, 128x128x4st, 256x256x2st, 256x128x3st}, 4..7 = "pipelined" loop {128x128x2st, 128x128x3st,
+ * 256x256x2st, 256x128x3st}; -1 = shape heuristic (default).  rr_set_gemm_stamps: DEVICE buffer of 4 uint64
+ * per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
+ * Both are process-wide and diagnostic. */
+int rr_set_gemm_variant(int variant);
+int rr_set_gemm_stamps(void* device_buf);
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream);
 

@@ -2,7 +2,7 @@
 
 Only what the hot path needs lives here: `csrc/` (HIP kernels + the C ABI of librerank_mi355.so),
 `_lib.py` (ctypes declarations), `model.py` (mirror of the reference's RerankerClass interface),
-`tokenize.py` (pair-input assembly), `sharding.py` (pair sharding + score all-gather across ranks).
+`pair_inputs.py` (pair-input assembly), `sharding.py` (pair sharding + score all-gather across ranks).
 Importing the package does not need a GPU; constructing a model does (no CPU fallback exists).
 """
 from ._lib import EXPORTED, LIB_PATH  # noqa: F401

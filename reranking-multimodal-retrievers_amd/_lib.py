@@ -64,6 +64,8 @@ _SIGS = {
     "rr_op_gemm_resid_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rr_op_attention_bf16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _P, C.c_int, _P]),
+    "rr_set_gemm_variant": (C.c_int, [C.c_int]),
+    "rr_set_gemm_stamps": (C.c_int, [_P]),
     "rr_op_layernorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
 }
 EXPORTED = sorted(_SIGS)

@@ -352,7 +352,7 @@ class FullContextRerankModel(torch.nn.Module):
             assert len(labels) == expanded
         if self.query_tokenizer is None:
             raise RuntimeError("text call signature needs config.tokenizer (an HF-style BERT tokenizer)")
-        from .tokenize import prepare_full_context_inputs
+        from .pair_inputs import prepare_full_context_inputs
         enc = prepare_full_context_inputs(query_text_sequences, context_text_sequences, self.query_tokenizer,
                                           self.max_query_length, self.max_context_length,
                                           self.max_decoder_source_length, num_negative_examples + 1)
