@@ -23,8 +23,11 @@ def prepare_full_context_inputs(query_text_sequences: List[str], context_text_se
     queries = [clip(t, max_query_length) for t in query_text_sequences]
     contexts = [clip(t, max_context_length) for t in context_text_sequences]
     pairs = [(q, contexts[i * docs_per_query + j]) for i, q in enumerate(queries) for j in range(docs_per_query)]
-    enc = tokenizer.batch_encode_plus(pairs, add_special_tokens=True, return_tensors="pt", padding="max_length",
-                                      truncation=True, max_length=max_decoder_source_length,
-                                      return_attention_mask=True, return_token_type_ids=True)
+    kw = dict(add_special_tokens=True, return_tensors="pt", padding="max_length", truncation=True,
+              max_length=max_decoder_source_length, return_attention_mask=True, return_token_type_ids=True)
+    if hasattr(tokenizer, "batch_encode_plus"):          # transformers 4.x (the reference pins 4.38.2)
+        enc = tokenizer.batch_encode_plus(pairs, **kw)
+    else:                                                # transformers 5.x dropped it; __call__ is equivalent
+        enc = tokenizer([q for q, _ in pairs], [c for _, c in pairs], **kw)
     return {"input_ids": enc["input_ids"].to(torch.int64), "attention_mask": enc["attention_mask"].to(torch.int64),
             "token_type_ids": enc["token_type_ids"].to(torch.int64)}

@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library builds, loads, exports every symbol include/rerank_mi355.h declares, and the product
+path refuses to run without a GPU (no fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()                                   # hipcc cross-compiles gfx950 without a GPU
+    from rmr_amd import _lib
+    return _lib.load()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "rerank_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from rmr_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rerank_mi355.h but not exported"
+    assert set(names) == set(_lib.EXPORTED), "ctypes table and header disagree"
+
+
+def test_version_and_status_strings(lib):
+    assert b"gfx950" in lib.rr_version()
+    assert lib.rr_status_string(0) == b"ok"
+    assert lib.rr_status_string(-2) == b"bad shape"
+
+
+def test_config_struct_layout_matches_header():
+    from rmr_amd import _lib
+    # 8 + 1 + 1 + 12 + 1 + 1 + 7 four-byte fields
+    assert C.sizeof(_lib.RRConfig) == 4 * 31
+    assert C.sizeof(_lib.RRProfile) == 8 * 6 * 4
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import rmr_amd
+    from rmr_amd import _lib
+    c = _lib.RRConfig()
+    c.abi_version = 1
+    for k, v in dict(vocab_size=100, hidden=128, layers=1, heads=2, intermediate=256, max_pos=64, type_vocab=2,
+                     li_dim=64, ce_hidden=128, ce_layers=1, ce_heads=2, ce_intermediate=256, ce_max_pos=64).items():
+        setattr(c, k, v)
+    h = C.c_void_p()
+    rc = lib.rr_create(C.byref(c), C.byref(h))
+    assert rc == _lib.RR_ERR_NO_DEVICE and not h.value
+    assert b"no CPU path" in lib.rr_last_error(None)
+    with pytest.raises(RuntimeError):
+        rmr_amd.RerankEngine(rmr_amd.make_arch())
+    with pytest.raises(RuntimeError):
+        rmr_amd.FullContextRerankModel(dict(loss_fn="BCE"))
+
+
+def test_bad_abi_version_rejected(lib):
+    from rmr_amd import _lib
+    c = _lib.RRConfig()
+    c.abi_version = 99
+    h = C.c_void_p()
+    assert lib.rr_create(C.byref(c), C.byref(h)) == _lib.RR_ERR_BAD_ARG
+    assert lib.rr_create(None, C.byref(h)) == _lib.RR_ERR_BAD_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import it."""
+    pkg = os.path.join(ROOT, "reranking-multimodal-retrievers_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("test oracle", "").replace("the oracle's scheme", ""), f
+    assert "oracle" not in open(os.path.join(ROOT, "rmr_amd.py")).read()
+
+
+def test_weight_spec_matches_library_required_names():
+    """Host-side name table == the reference state_dict keys the C side asks for (checked without a GPU by
+    parsing the names out of the C source is brittle; instead compare with the oracle's independent table)."""
+    import rmr_amd
+    from oracle import rerank_oracle as O
+    a = rmr_amd.make_arch(dict(loss_fn="BCE"))
+    ours = [(n, tuple(s)) for n, s, _ in rmr_amd.weight_spec(a)]
+    theirs = [(n, tuple(s)) for n, s, _ in O.weight_spec(O.OracleConfig(), vision=True)]
+    assert ours == theirs
+    assert len(ours) == 5 + 12 * 16 + 1 + 6 + 26 + 2 + 2 + 4 + 16 + 4
+    sd = rmr_amd.synthetic_state_dict(rmr_amd.make_arch(dict(loss_fn="BCE"), layers=1, vocab_size=50), seed=3,
+                                      hf_init=False)
+    ref = O.make_weights(O.OracleConfig(layers=1, vocab_size=50), seed=3, vision=True)
+    assert all((sd[k] == ref[k]).all() for k in ref) and set(sd) == set(ref)

@@ -1,0 +1,49 @@
+"""CPU: pair-input assembly restated from utils.py:129-167, exercised with a locally generated WordPiece vocab
+(no vocab file exists offline)."""
+import os
+
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def tok(tmp_path_factory):
+    from transformers import BertTokenizer
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    words += ["what", "is", "the", "color", "of", "this", "bus", "red", "a", "big", "city", "street", "in", "london",
+              "double", "decker", ".", ",", "?", "##s", "##es", "buses", "are", "usually", "image", "query"]
+    d = tmp_path_factory.mktemp("vocab")
+    f = os.path.join(d, "vocab.txt")
+    open(f, "w").write("\n".join(words) + "\n")
+    return BertTokenizer(f, do_lower_case=True)
+
+
+def test_pair_encoding_layout(tok):
+    from rmr_amd.pair_inputs import prepare_full_context_inputs
+    q = ["what is the color of this bus ?"]
+    ctx = ["london buses are usually red .", "a big city street in london " * 10, ""]
+    enc = prepare_full_context_inputs(q, ctx, tok, max_query_length=4, max_context_length=12,
+                                      max_decoder_source_length=24, docs_per_query=3)
+    ids, am, tt = enc["input_ids"], enc["attention_mask"], enc["token_type_ids"]
+    assert ids.shape == am.shape == tt.shape == (3, 24) and ids.dtype == torch.int64
+    cls, sep, pad = tok.cls_token_id, tok.sep_token_id, tok.pad_token_id
+    assert pad == 0 and (ids[:, 0] == cls).all()
+    for n in range(3):
+        row = ids[n].tolist()
+        first_sep = row.index(sep)
+        assert first_sep == 1 + 4                                   # query truncated to 4 tokens
+        assert tt[n, : first_sep + 1].sum() == 0                    # [CLS] q [SEP] -> type 0
+        L = int(am[n].sum())
+        assert row[L - 1] == sep and all(t == pad for t in row[L:])
+        assert (tt[n, first_sep + 1: L] == 1).all() and tt[n, L:].sum() == 0
+        assert (am[n] == (ids[n] != 0).long()).all()
+    assert int(am[1].sum()) == 1 + 4 + 1 + 12 + 1                   # context truncated to 12 tokens
+    assert int(am[2].sum()) == 1 + 4 + 1 + 0 + 1                    # empty context
+
+
+def test_query_major_order(tok):
+    from rmr_amd.pair_inputs import prepare_full_context_inputs
+    enc = prepare_full_context_inputs(["red bus", "big city"], ["a", "the", "london", "street"], tok, 8, 8, 16, 2)
+    ids = enc["input_ids"]
+    red, big = tok.convert_tokens_to_ids("red"), tok.convert_tokens_to_ids("big")
+    assert (ids[:2, 1] == red).all() and (ids[2:, 1] == big).all()
