@@ -191,6 +191,7 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
  * Both are process-wide and diagnostic. */
 int rr_set_gemm_variant(int variant);
 int rr_set_gemm_stamps(void* device_buf);
+int rr_set_gemm_stagger(int unit);   /* start skew of the first dispatch wave, in s_sleep(127) units; 0 = off */
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream);
 

@@ -66,6 +66,7 @@ _SIGS = {
                                        C.c_int, _P, C.c_int, _P]),
     "rr_set_gemm_variant": (C.c_int, [C.c_int]),
     "rr_set_gemm_stamps": (C.c_int, [_P]),
+    "rr_set_gemm_stagger": (C.c_int, [C.c_int]),
     "rr_op_layernorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
 }
 EXPORTED = sorted(_SIGS)

@@ -84,10 +84,23 @@ __device__ __forceinline__ float fast_erf(float x) {
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
 }
+// tanh(x) = 1 - 2/(exp(2x)+1) on the fast exp/rcp units (abs err ~1e-7; saturates correctly at +-inf)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 // ---- diagnostic cycle stamps (tools/bench_gemm.py --stamps): block entry / first tile ready / main loop done /
 // epilogue done, written by lane 0 of wave 0 into a buffer no kernel reads.  nullptr in every product launch.
+// De-synchronise the CUs: all workgroups of the first dispatch wave would otherwise reach their store epilogue at
+// the same instant and fight for HBM write bandwidth (measured: 128 KiB/CU epilogues run at the chip-wide
+// HBM write rate while the main loops leave HBM idle).  Workgroup b of the first `first_wave` ones sleeps
+// ((b>>3)&7) * unit cycles once; later workgroups inherit the skew because they start when a CU frees up.
+__device__ __forceinline__ void start_stagger(int first_wave, int unit_sleeps) {
+  if ((int)blockIdx.x < first_wave) {
+    const int n = ((blockIdx.x >> 3) & 7) * unit_sleeps;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles each
+  }
+}
+
 __device__ __forceinline__ void stamp(unsigned long long* stamps, int slot) {
   if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
@@ -100,7 +113,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, int ldr,
                                                              void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                             int tiles_n, int nwg, unsigned long long* stamps) {
+                                                             int tiles_n, int nwg, unsigned long long* stamps,
+                                                             int stagger_unit) {
+  if (stagger_unit > 0) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
         float v0 = acc[nt][mt][4 * g + 0] + bv.x, v1 = acc[nt][mt][4 * g + 1] + bv.y,
               v2 = acc[nt][mt][4 * g + 2] + bv.z, v3 = acc[nt][mt][4 * g + 3] + bv.w;
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-        if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3); }
+        if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
         if (EPI == EPI_BIAS_RESID_F32) {
           const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
           v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -259,13 +274,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
 
 // Variant S ("simple"): 16x16x32 MFMA, tile barrier at the top of each K-tile, fragment reads scheduled by the
 // compiler inside the tile.
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool LDS_EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __restrict__ A, int lda,
                                                              const bf16_t* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ resid, int ldr,
                                                              void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                             int tiles_n, int nwg, unsigned long long* stamps) {
+                                                             int tiles_n, int nwg, unsigned long long* stamps,
+                                                             int stagger_unit) {
+  if (stagger_unit > 0) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -352,6 +369,72 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
   stamp(stamps, 2);
   if (stamps && threadIdx.x == 0) { stamps[(size_t)blockIdx.x * 8 + 4] = t_wait; stamps[(size_t)blockIdx.x * 8 + 5] = t_bar; }
 
+  constexpr bool F32_OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32);
+  if constexpr (LDS_EPI) {
+    // ---- epilogue through LDS: the direct form issues 32 scattered 8-byte stores per lane (16 rows x 32 B per
+    // wave-instruction) and measured store-ISSUE-bound at ~9 B/clk/CU.  Here each wave group drops its finished
+    // values (bias/activation applied, final dtype) into a row-major staging image, then all waves stream it out
+    // as 16 B per lane along rows: every wave-instruction covers whole 512-byte (bf16) / 1-KiB (f32) row segments,
+    // and the fp32 residual is read with the same coalesced pattern and added on the way out.
+    constexpr int ES = F32_OUT ? 4 : 2;
+    constexpr int PITCH = BN * ES + 16;                       // +16 B: rows start on different banks
+    constexpr int CPR = BN * ES / 16;                         // 16-byte chunks per row
+    constexpr int NTHR = NW * 64;
+    // bf16 images of all WM row groups fit LDS at once (256 x 528 B); f32 images go one row group at a time
+    constexpr int NPASS = F32_OUT ? WM : 1;
+    constexpr int ROWS = F32_OUT ? TM : BM;
+    // (1) every wave finishes its own values first (bias + activation, final dtype) so that the GELU/tanh VALU work
+    //     of all 8 waves runs concurrently rather than one row group at a time
+    uint2 pk[F32_OUT ? 1 : NT][F32_OUT ? 1 : MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
+      const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
+              v3 = acc[nt][mt][3] + bv.w;
+        if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+        if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+        if constexpr (F32_OUT) acc[nt][mt] = f32x4{v0, v1, v2, v3};
+        else pk[nt][mt] = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+      }
+    }
+    __builtin_amdgcn_s_barrier();                             // all MFMA-phase LDS reads are complete
+    for (int pass = 0; pass < NPASS; ++pass) {
+      if (!F32_OUT || wm == pass) {
+        const int rbase = F32_OUT ? 0 : wm * TM;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int cn = wn * TN + nt * 16 + (lane >> 4) * 4;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            char* dst = lds + (rbase + mt * 16 + (lane & 15)) * PITCH + cn * ES;
+            if constexpr (F32_OUT) *(f32x4*)dst = acc[nt][mt];
+            else *(uint2*)dst = pk[nt][mt];
+          }
+        }
+      }
+      __syncthreads();
+      const int row_base = m0 + (F32_OUT ? pass * TM : 0);
+#pragma unroll 4
+      for (int i = tid; i < ROWS * CPR; i += NTHR) {
+        const int r = i / CPR, c = i - r * CPR;
+        const int gm = row_base + r, gcol = n0 + c * (16 / ES);
+        if (gm < M && gcol < N) {
+          uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
+          if (EPI == EPI_BIAS_RESID_F32) {
+            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gcol);
+            float4 f = __builtin_bit_cast(float4, v);
+            f.x += rv.x; f.y += rv.y; f.z += rv.z; f.w += rv.w;
+            v = __builtin_bit_cast(uint4, f);
+          }
+          *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+        }
+      }
+      if (pass + 1 < NPASS) __syncthreads();
+    }
+  } else {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
@@ -364,7 +447,144 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
             v3 = acc[nt][mt][3] + bv.w;
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanhf(v0); v1 = tanhf(v1); v2 = tanhf(v2); v3 = tanhf(v3); }
+      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+      if (EPI == EPI_BIAS_RESID_F32) {
+        const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
+        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+      }
+      if (F32_OUT) {
+        *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
+      } else {
+        *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+      }
+    }
+  }
+  }
+  stamp(stamps, 3);
+}
+
+// Variant G ("group-staggered"): 256x256x32 K-tiles in a STAGES-deep LDS ring (32 KiB each), 8 waves as two
+// groups (waves 0-3 / 4-7 = the two waves of every SIMD).  Every K-tile has a LOAD segment (12 ds_read_b128 +
+// this wave's 4 DMA pieces for the tile STAGES-1 ahead) and a COMPUTE segment (32 MFMAs) separated by barriers,
+// and group 1 runs one barrier behind group 0: while one wave of a SIMD issues MFMAs its partner reads LDS, so
+// the matrix pipe never waits for fragment loads, and the DMA of a tile has STAGES-2 full iterations to land
+// (MI355X_MICROARCH.md "Two waves per SIMD").  Hazards: RAW — every wave waits (counted vmcnt) for its pieces
+// of tile j before the barrier that precedes the first read of tile j; WAR — tile j-1's buffer is refilled
+// only in LOAD(j), i.e. after the barrier that follows group 1's lgkmcnt(0) of LOAD(j-1).  Both groups execute
+// exactly 2*nk+1 barriers.
+__device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4); }
+
+template <int STAGES, int EPI>
+__global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ A, int lda,
+                                                     const bf16_t* __restrict__ W, int ldw,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ resid, int ldr,
+                                                     void* __restrict__ Cv, int ldc, int M, int N, int Kd,
+                                                     int tiles_n, int nwg, unsigned long long* stamps) {
+  stamp(stamps, 0);
+  constexpr int BM = 256, BN = 256, BKG = 32, WN = 4;
+  constexpr int TM = 128, TN = 64, MT = 8, NT = 4;
+  constexpr int A_BYTES = BM * BKG * 2, STAGE_BYTES = (BM + BN) * BKG * 2;   // 16 KiB + 16 KiB
+  constexpr int PIECES = 4;                                                   // 2 A + 2 W pieces (16 rows x 64 B) per wave
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // 0: waves 0-3, 1: waves 4-7
+  const int wm = wave / WN, wn = wave % WN;
+
+  // staging: piece p of this wave = rows (wave*2 + p)*16 .. +15, lane -> (row = lane>>2, slot = lane&3)
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+    a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+    w_src[i] = W + (size_t)min(n0 + r, N - 1) * ldw + c * 8;
+  }
+  const uint32_t lds_base = lds_addr(lds);
+  auto stage = [&](int buf, int k0) {
+    const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 2048);
+    const uint32_t w_dst = a_dst + A_BYTES;
+    glds16(a_src[0] + k0, a_dst);
+    glds16(a_src[1] + k0, a_dst + 1024);
+    glds16(w_src[0] + k0, w_dst);
+    glds16(w_src[1] + k0, w_dst + 1024);
+  };
+  const int nk = Kd / BKG;
+  auto wait_for_tile = [&](int j) {                 // my pieces of tile j have landed
+    const int inflight = min(nk - 1, j + STAGES - 2) - j;
+    if (inflight >= 3) wait_vmcnt<3 * PIECES>();
+    else if (inflight == 2) wait_vmcnt<2 * PIECES>();
+    else if (inflight == 1) wait_vmcnt<PIECES>();
+    else wait_vmcnt<0>();
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s * BKG);
+
+  // fragment addresses: lane reads row (lane&15) of a 16-row block, chunk lane>>4; the swizzle term is the same
+  // for every 16-row block, so block t is a +1024-byte immediate
+  const int a_off = swz64(wm * TM + (lane & 15), lane >> 4);
+  const int w_off = A_BYTES + swz64(wn * TN + (lane & 15), lane >> 4);
+
+  if (grp == 1) {
+    wait_for_tile(0);
+    __builtin_amdgcn_s_barrier();                   // stagger: group 1 runs one barrier behind
+  }
+  for (int j = 0; j < nk; ++j) {
+    if (grp == 0) wait_for_tile(j);
+    __builtin_amdgcn_s_barrier();                   // B1(j)
+    if (j == 0) stamp(stamps, 1);
+    const char* tb = lds + (j % STAGES) * STAGE_BYTES;
+    bf16x8 af[MT], wf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(tb + w_off + t * 1024);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(tb + a_off + t * 1024);
+    if (j + STAGES - 1 < nk) stage((j + STAGES - 1) % STAGES, (j + STAGES - 1) * BKG);
+    if (grp == 1 && j + 1 < nk) wait_for_tile(j + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                   // B2(j)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();       // both groups: 2*nk + 1 barriers
+  stamp(stamps, 2);
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
+    if (gn >= N) continue;
+    float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int gm = m0 + wm * TM + mt * 16 + (lane & 15);
+      if (gm >= M) continue;
+      float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
+            v3 = acc[nt][mt][3] + bv.w;
+      if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
       if (EPI == EPI_BIAS_RESID_F32) {
         const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
         v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -380,17 +600,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
 }
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
+int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE>
-hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
-                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
-  constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2;
-  dim3 grid(nwg), block(WM * WN * 64);
+template <int STAGES>
+hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+  if (Kd % 32 != 0) return hipErrorInvalidValue;
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
+  constexpr int lds_bytes = STAGES * 512 * 32 * 2;
+  dim3 grid(nwg), block(512);
   unsigned long long* stamps = g_stamps;
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
-    auto kern = PIPE ? gemm_kernel_p<BM, BN, WM, WN, STAGES, E> : gemm_kernel_s<BM, BN, WM, WN, STAGES, E>;                                                       \
+    auto kern = gemm_kernel_g<STAGES, E>;                                                                     \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -413,14 +635,58 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   return hipGetLastError();
 }
 
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool LDS_EPI = false>
+hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+  constexpr int ring_bytes = STAGES * (BM + BN) * BK * 2;
+  // staging image: f32 -> one row group (BM/WM rows x (4 BN + 16) B); bf16 -> the whole tile (BM x (2 BN + 16) B)
+  constexpr int stage_f32 = (BM / WM) * (BN * 4 + 16), stage_b16 = BM * (BN * 2 + 16);
+  constexpr int stage_out_bytes = LDS_EPI ? (stage_f32 > stage_b16 ? stage_f32 : stage_b16) : 0;
+  constexpr int lds_bytes = ring_bytes > stage_out_bytes ? ring_bytes : stage_out_bytes;
+  static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+  if (LDS_EPI && (N & 7)) return hipErrorInvalidValue;
+  dim3 grid(nwg), block(WM * WN * 64);
+  unsigned long long* stamps = g_stamps;
+#define RR_GEMM_CASE(E)                                                                                       \
+  case E: {                                                                                                   \
+    auto kern = PIPE ? gemm_kernel_p<BM, BN, WM, WN, STAGES, E> : gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI>;                                                       \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      if (e != hipSuccess) return e;                                                                          \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
+                       tiles_n, nwg, stamps, (BM == 256 && BN == 256 && nwg > 512) ? g_stagger : 0);         \
+    break;                                                                                                    \
+  }
+  switch (epilogue) {
+    RR_GEMM_CASE(EPI_BIAS_BF16)
+    RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
+    RR_GEMM_CASE(EPI_BIAS_F32)
+    RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
+    RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    default: return hipErrorInvalidValue;
+  }
+#undef RR_GEMM_CASE
+  return hipGetLastError();
+}
+
 int g_variant = -1;   // tuning override: RR_GEMM_VARIANT=0..3 (unset: shape heuristic)
 
 }  // namespace
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 7) return -1;
+  if (v < -1 || v > 10) return -1;
   g_variant = v;
+  return 0;
+}
+extern "C" int rr_set_gemm_stagger(int unit) {
+  if (unit < 0 || unit > 64) return -1;
+  g_stagger = unit;
   return 0;
 }
 // diagnostic: DEVICE buffer of 4 x uint64 per workgroup receiving cycle stamps, or NULL to switch off
@@ -443,9 +709,11 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   }
   int v = g_variant;
   if (v < 0) {
-    // big problems: 256x256 tiles (1 workgroup/CU, 8 waves); small ones: 128x128 so the grid still fills 256 CUs
+    // big problems: 256x256 tiles (1 workgroup/CU, 8 waves); small ones: 128x128 so the grid still fills 256 CUs.
+    // Epilogue: LDS-staged coalesced stores, except GELU whose ~18k cycles of VALU work per tile hide best behind
+    // the direct form's store issue (measured, tools/bench_gemm.py --stamps).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    v = tiles256 >= 512 ? 2 : 0;
+    v = tiles256 >= 512 ? ((epilogue == EPI_BIAS_GELU_BF16 || (N & 7)) ? 2 : 10) : 0;
   }
 #define RR_CFG(BM_, BN_, WM_, WN_, ST_, P_) \
   return launch_cfg<BM_, BN_, WM_, WN_, ST_, P_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st)
@@ -458,6 +726,9 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     case 5: RR_CFG(128, 128, 2, 2, 3, true);
     case 6: RR_CFG(256, 256, 2, 4, 2, true);
     case 7: RR_CFG(256, 128, 4, 2, 3, true);
+    case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+    case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+    case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
     default: return hipErrorInvalidValue;
   }
 #undef RR_CFG

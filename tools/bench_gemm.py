@@ -15,14 +15,17 @@ from rmr_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=800)
 ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--variants", default="0,2,3,4,6,7")
+ap.add_argument("--variants", default="2,8,9")
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--stagger", default="0")
 a = ap.parse_args()
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 M = a.pairs * 512
 shapes = [("qkv", 2304, 768, 0), ("attn_out", 768, 768, 4), ("ffn1", 3072, 768, 1), ("ffn2", 768, 3072, 4)]
 variants = [int(v) for v in a.variants.split(",")]
+staggers = [int(v) for v in a.stagger.split(",")]
+variants = [(v, sg) for v in variants for sg in staggers]
 g = torch.Generator().manual_seed(0)
 for name, N, K, epi in shapes:
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -41,7 +44,7 @@ for name, N, K, epi in shapes:
     ref = None
     for r in range(a.rounds + 1):
         for v in variants:
-            assert lib.rr_set_gemm_variant(v) == 0
+            assert lib.rr_set_gemm_variant(v[0]) == 0 and lib.rr_set_gemm_stagger(v[1]) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
@@ -58,7 +61,7 @@ for name, N, K, epi in shapes:
     fl = 2.0 * M * N * K
     if a.stamps:
         for v in variants:
-            lib.rr_set_gemm_variant(v)
+            lib.rr_set_gemm_variant(v[0]); lib.rr_set_gemm_stagger(v[1])
             buf = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
             lib.rr_set_gemm_stamps(buf.data_ptr())
             run()
@@ -73,4 +76,4 @@ for name, N, K, epi in shapes:
     print(f"{name:9s} M={M} N={N} K={K}: " + "  ".join(
         f"v{v}: {min(t):.3f} ms {fl / min(t) / 1e9:7.1f} TF (med {fl / sorted(t)[len(t) // 2] / 1e9:6.1f})" for v, t in res.items()),
         flush=True)
-lib.rr_set_gemm_variant(-1)
+lib.rr_set_gemm_variant(-1); lib.rr_set_gemm_stagger(0)
