@@ -47,17 +47,18 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
                                                        int q_batch_div, int q_batch_off,
                                                        const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, int kv_stride,
                                                        const float* __restrict__ key_bias, int heads,
                                                        int Tq, int Tk, bf16_t* __restrict__ out,
                                                        int out_stride) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4];
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
-  float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64]
+  float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64] raw additive key bias
+  int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);   // [2] tile has a masked / out-of-range key
 
   const int b = blockIdx.z, head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     vr0 = *(const uint4*)(vbase + off0); vr1 = *(const uint4*)(vbase + off1);                   \
     if (tid < KT) {                                                                             \
       const int key = (t) * KT + tid;                                                           \
-      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] * LOG2E : 0.f) : -INFINITY;    \
+      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;    \
     }                                                                                           \
   }
 #define RR_WRITE_TILE(buf)                                                                      \
@@ -94,7 +95,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     *(uint4*)(k_img + (buf) * TILE_BYTES + swz128(srow1, sc)) = kr1;                            \
     *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow0, sc)) = vr0;                              \
     *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow1, sc)) = vr1;                              \
-    if (tid < KT) b_img[(buf) * KT + tid] = br;                                                 \
+    if (tid < KT) {                                                                             \
+      b_img[(buf) * KT + tid] = br;                                                             \
+      const unsigned long long any = __ballot(br != 0.f);      /* wave 0 only: tid < 64 */     \
+      if (tid == 0) f_img[buf] = any != 0ull;                                                   \
+    }                                                                                           \
   }
 
   f32x16 o0, o1;   // O^T[d = 32*dblk + (r&3) + 8(r>>2) + 4h][query = lane&31]
@@ -124,30 +129,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[i], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[i], s1, 0, 0, 0);
     }
-    // ---- log2-domain scores + key bias, tile row max
-    float mx = -INFINITY;
+    // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
+    // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
+    const bool masked = f_img[buf] != 0;             // wave-uniform: some key of this tile carries a bias
+    float mx;
+    if (masked) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
-      const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
-      s0[4 * g + 0] = fmaf(s0[4 * g + 0], LOG2E, b0.x); s0[4 * g + 1] = fmaf(s0[4 * g + 1], LOG2E, b0.y);
-      s0[4 * g + 2] = fmaf(s0[4 * g + 2], LOG2E, b0.z); s0[4 * g + 3] = fmaf(s0[4 * g + 3], LOG2E, b0.w);
-      s1[4 * g + 0] = fmaf(s1[4 * g + 0], LOG2E, b1.x); s1[4 * g + 1] = fmaf(s1[4 * g + 1], LOG2E, b1.y);
-      s1[4 * g + 2] = fmaf(s1[4 * g + 2], LOG2E, b1.z); s1[4 * g + 3] = fmaf(s1[4 * g + 3], LOG2E, b1.w);
+      for (int g = 0; g < 4; ++g) {
+        const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
+        const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
+        s0[4 * g + 0] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
+        s1[4 * g + 0] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
+      }
     }
+    mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 in-range key
-    const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    const float m_new = fmaxf(m_run, mx);            // finite: every tile has >= 1 in-range key
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // first tile: exp2(-inf) = 0
     m_run = m_new;
+    if (masked) {
+      // (s + bias) - m is exactly 0 for a fully masked row (all entries -1e30): uniform attention, as the
+      // reference's finfo.min mask gives; a fused multiply-add form would not cancel exactly.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
+        s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
+      }
+    } else {
+      const float c = -m_new * LOG2E;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c));
+      }
+    }
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = exp2f(s0[r] - m_new);
-      s1[r] = exp2f(s1[r] - m_new);
-      ps += s0[r] + s1[r];
-    }
+    for (int r = 0; r < 16; ++r) ps += s0[r] + s1[r];
     l_run = l_run * alpha + ps;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }

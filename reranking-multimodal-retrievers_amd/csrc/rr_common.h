@@ -20,7 +20,10 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
   return __builtin_bit_cast(float, ((uint32_t)b) << 16);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));   // one v_cvt_pk_bf16_f32
 }
 
 // LDS byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64 x bf16] tile image
