@@ -113,8 +113,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ    # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     import rmr_amd
@@ -139,12 +141,12 @@ def main():
         cls, pat = cls.to(dev), pat.to(dev)
 
     def step():
-        if world > 1:
-            return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None)
+        if distributed:      # also with one rank: the same slice -> all-gather -> head path the N-GPU runs take
+            return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None, want_scores=True)
         return eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -159,7 +161,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
     prof = eng.get_profile(reset=True) if not args.no_profile else None
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -200,7 +202,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(arch, sd, K, S, vision, args.cpu_pairs)
             res["gpu_over_cpu"] = pairs_per_s / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

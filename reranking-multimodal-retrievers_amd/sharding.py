@@ -25,8 +25,6 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None) -> torch.Tensor
     """All-gather ragged per-rank logit slices into the full [n_pairs] vector with one collective:
     slices are padded to ceil(N/W) so a single all_gather_into_tensor suffices."""
     world = dist.get_world_size(group)
-    if world == 1:
-        return local
     per = -(-n_pairs // world)
     buf = torch.zeros(per, dtype=local.dtype, device=local.device)
     buf[: local.numel()] = local
