@@ -49,6 +49,20 @@ def flops_per_pair(a, S, vision):
     return f
 
 
+def pmc_traffic_gb(kernel_class):
+    """HBM-side bytes per launch of a kernel class from the newest committed PMC pass (profiles/*_hbm_traffic.json,
+    produced by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))["per_kernel_class"][kernel_class]
+        return d["hbm_bytes_per_launch"] / 1e9
+    except Exception:
+        return None
+
+
 def host_cores():
     """CPU threads this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
     try:
@@ -190,7 +204,9 @@ def main():
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             res["roofline"] = {"bound": "mfma", "kernel": "gemm128_kernel (bf16 MFMA GEMM + fused epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_gb("gemm"),
+                               "traffic_unit": "GB per launch beyond L2 (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
+                               "algorithmic_gb_per_launch": g["bytes"] / max(1, g["launches"]) / 1e9,
                                "launches": g["launches"], "avg_launch_ms": g["ms"] / max(1, g["launches"]),
                                "avg_launch_gflop": g["flops"] / max(1, g["launches"]) / 1e9,
                                "note": "per-launch HIP events on the work stream inside the timed region, rank 0"}
