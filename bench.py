@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit MFMA operand type of the timed run (north_star: bf16)")
+    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra fp16-operand timing (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +142,8 @@ def main():
 
     vision = not args.text_only
     arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750,
-                                  loss_fn="BCE", pos_weight=None), has_vision=int(vision))
+                                  loss_fn="BCE", pos_weight=None), has_vision=int(vision),
+                             compute_dtype=args.compute_dtype)
     sd = rmr_amd.synthetic_state_dict(arch, seed=0, hf_init=True)
     eng = rmr_amd.RerankEngine(arch, dev)
     eng.load_state_dict(sd)
@@ -188,7 +192,7 @@ def main():
             "metric": "reranked query x candidate pairs/sec at K=100, seq_len=512",
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.compute_dtype, "data": "synthetic",
             "config": {"workload": ("c3: FLMR multimodal query cross-encoder rerank" if vision
                                     else "c3-text: text-only cross-encoder rerank")
                        + f" (monoPreFLMR-B shape, Lc=1), K={K}, seq_len={S}, vision_tokens={81 if vision else 0}",
@@ -214,6 +218,23 @@ def main():
             res["kernel_time_share"] = {k: (v["ms"] / tot if tot else 0.0) for k, v in prof.items()}
             a = prof["attention"]
             res["attention_tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+        if world == 1 and not args.no_alt_dtype and args.compute_dtype == "bf16":
+            # same kernels with fp16 MFMA operands (the mode that meets 1e-3 against the fp32 reference logits)
+            del eng
+            torch.cuda.empty_cache()
+            eng2 = rmr_amd.RerankEngine(dict(arch, compute_dtype="fp16"), dev)
+            eng2.load_state_dict(sd)
+            for _ in range(max(1, args.warmup)):
+                eng2.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng2.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
+            torch.cuda.synchronize(dev)
+            res["fp16_operand_mode"] = {"value": N * args.steps / (time.perf_counter() - t1), "unit": "pairs/s",
+                                        "note": "compute_dtype=fp16: logits within 1e-3 of the fp32 HF goldens "
+                                                "(tests/test_gpu_forward.py)"}
+            del eng2
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(arch, sd, K, S, vision, args.cpu_pairs)
             res["gpu_over_cpu"] = pairs_per_s / res["cpu_baseline"]["value"]

@@ -81,7 +81,11 @@ typedef struct rr_config {
   int32_t loss_kind;          /* rr_loss_kind */
   float pos_weight;           /* NaN = none (utils.py:210,215) */
   int32_t device;             /* HIP device ordinal */
-  int32_t reserved[7];
+  int32_t compute_dtype;      /* 16-bit MFMA operand type: 0 = bf16 (default; the reference runs bf16-mixed),
+                                 1 = fp16 (same MFMA rate, 3 more mantissa bits: logits within 1e-3 of the fp32
+                                 forward; range +-65504 is ample for BERT activations, accumulation/residual/
+                                 LayerNorm/softmax stay fp32 in both modes) */
+  int32_t reserved[6];
 } rr_config;
 
 typedef struct rr_model* rr_handle;
@@ -190,6 +194,7 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
  * per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
  * Both are process-wide and diagnostic. */
 int rr_set_gemm_variant(int variant);
+int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_gemm_stagger(int unit);   /* start skew of the first dispatch wave, in s_sleep(127) units; 0 = off */
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,

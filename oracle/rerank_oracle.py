@@ -116,8 +116,11 @@ def multi_head_attention(q: Tensor, k: Tensor, v: Tensor, heads: int,
 # two hooks reproduce exactly those rounding points on top of the fp32 restatement so that parity
 # tests can separate "bf16 operand rounding" (inherent, shared with the reference's bf16-mixed runs)
 # from kernel bugs.
+_RDT = [torch.bfloat16]          # 16-bit operand dtype being emulated (device compute_dtype)
+
+
 def _bf(x: Tensor) -> Tensor:
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(_RDT[-1]).to(torch.float32)
 
 
 def mm_bf16(x: Tensor, W: Tensor) -> Tensor:
@@ -146,14 +149,20 @@ _MHA = [multi_head_attention]
 
 
 class device_rounding:
-    """`with device_rounding() as mm:` — run the oracle with the device's bf16 rounding points."""
+    """`with device_rounding(dtype) as mm:` — run the oracle with the device's 16-bit rounding points
+    (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16")."""
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
 
     def __enter__(self):
         _MHA.append(multi_head_attention_bf16)
+        _RDT.append(self.dtype)
         return mm_bf16
 
     def __exit__(self, *a):
         _MHA.pop()
+        _RDT.pop()
         return False
 
 

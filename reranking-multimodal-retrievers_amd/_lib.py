@@ -18,6 +18,7 @@ RR_OK, RR_ERR_BAD_ARG, RR_ERR_BAD_SHAPE, RR_ERR_BAD_DTYPE, RR_ERR_UNSUPPORTED = 
 RR_ERR_HIP, RR_ERR_OOM, RR_ERR_MISSING_WEIGHT, RR_ERR_NO_DEVICE = -5, -6, -7, -8
 RR_F32, RR_BF16, RR_F16 = 0, 1, 2
 LOSS_KINDS = {"BCE": 0, "2H_BCE": 1, "negative_sampling": 2}
+COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
 KERNEL_CLASSES = ["gemm", "attention", "layernorm", "embed", "tail", "head"]
 
 
@@ -28,7 +29,8 @@ class RRConfig(C.Structure):
                [(n, C.c_int32) for n in ("ce_hidden", "ce_layers", "ce_heads", "ce_intermediate", "ce_max_pos",
                                          "has_vision", "vision_hidden", "prefix_len", "n_patches", "map_layers",
                                          "cross_attn_len", "loss_kind")] + \
-               [("pos_weight", C.c_float), ("device", C.c_int32), ("reserved", C.c_int32 * 7)]
+               [("pos_weight", C.c_float), ("device", C.c_int32), ("compute_dtype", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class RRProfile(C.Structure):
@@ -65,6 +67,7 @@ _SIGS = {
     "rr_op_attention_bf16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _P, C.c_int, _P]),
     "rr_set_gemm_variant": (C.c_int, [C.c_int]),
+    "rr_set_op_dtype": (C.c_int, [C.c_int]),
     "rr_set_gemm_stamps": (C.c_int, [_P]),
     "rr_set_gemm_stagger": (C.c_int, [C.c_int]),
     "rr_op_layernorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P]),

@@ -47,6 +47,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_
   return __builtin_bit_cast(bf16x8, r);
 }
 
+template <int DT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
                                                        int q_batch_div, int q_batch_off,
                                                        const bf16_t* __restrict__ k,
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < 4; ++i) {
       const bf16x8 k0 = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
       const bf16x8 k1 = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[i], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[i], s1, 0, 0, 0);
+      s0 = mfma32<DT>(k0, qf[i], s0);
+      s1 = mfma32<DT>(k1, qf[i], s1);
     }
     // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
     // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
@@ -184,15 +185,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         for (int j = 0; j < 4; ++j) {
           const float lo = kb == 0 ? s0[8 * s + 2 * j] : s1[8 * s + 2 * j];
           const float hi = kb == 0 ? s0[8 * s + 2 * j + 1] : s1[8 * s + 2 * j + 1];
-          pw[j] = pack2bf(lo, hi);
+          pw[j] = pack2<DT>(lo, hi);
         }
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         const int key0 = kb * 32 + 16 * s + 4 * h;
         const int cg = 2 * ((lane >> 4) & 1);      // 16-lane group -> d columns 16*(g&1) within the 32-d block
         const bf16x8 v0 = tr_pair(vt_, key0, 0 + cg, lane);   // d block 0: chunks 0..3
         const bf16x8 v1 = tr_pair(vt_, key0, 4 + cg, lane);   // d block 1: chunks 4..7
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
+        o0 = mfma32<DT>(v0, pf, o0);
+        o1 = mfma32<DT>(v1, pf, o1);
       }
     }
     if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     bf16_t* op = out + ((size_t)b * Tq + qrow) * out_stride + head * 64 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      *(uint2*)(op + 8 * g) = make_uint2(pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                         pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-      *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                              pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+      *(uint2*)(op + 8 * g) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                                         pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                                              pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
     }
   }
 }
@@ -218,12 +219,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
-                               int Tq, int Tk, bf16_t* out, int out_stride, hipStream_t st) {
+                               int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st) {
+  if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
   if (B > 65535 || heads > 65535) return hipErrorInvalidValue;
   dim3 grid((Tq + 127) / 128, heads, B), block(256);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
-                     key_bias, heads, Tq, Tk, out, out_stride);
+  if (dt == 0)
+    hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
+                       key_bias, heads, Tq, Tk, out, out_stride);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
+                       key_bias, heads, Tq, Tk, out, out_stride);
   return hipGetLastError();
 }

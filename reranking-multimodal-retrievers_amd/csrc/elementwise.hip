@@ -33,7 +33,7 @@ __device__ __forceinline__ RowStats row_stats(const float4 (&v)[MAX_V4], int n4,
 }
 
 __device__ __forceinline__ void ln_store(const float4 (&v)[MAX_V4], RowStats st, const float* gamma,
-                                         const float* beta, int n4, int lane, float* o32, bf16_t* o16) {
+                                         const float* beta, int n4, int lane, float* o32, bf16_t* o16, int dt) {
 #pragma unroll
   for (int i = 0; i < MAX_V4; ++i) {
     const int c4 = lane + 64 * i;
@@ -45,7 +45,7 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[MAX_V4], RowStats st,
       y.z = (v[i].z - st.mean) * st.rstd * g.z + b.z;
       y.w = (v[i].w - st.mean) * st.rstd * g.w + b.w;
       if (o32) ((float4*)o32)[c4] = y;
-      if (o16) ((uint2*)o16)[c4] = make_uint2(pack2bf(y.x, y.y), pack2bf(y.z, y.w));
+      if (o16) ((uint2*)o16)[c4] = make_uint2(pack2rt(y.x, y.y, dt), pack2rt(y.z, y.w, dt));
     }
   }
 }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[MAX_V4], RowStats st,
 // ---- LayerNorm over fp32 rows -> fp32 (residual stream) + bf16 (next GEMM operand)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows,
-                                                        int cols, float* __restrict__ o32, bf16_t* __restrict__ o16) {
+                                                        int cols, float* __restrict__ o32, bf16_t* __restrict__ o16, int dt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < MAX_V4; ++i) v[i] = (lane + 64 * i < n4) ? xr[lane + 64 * i] : make_float4(0, 0, 0, 0);
   const RowStats st = row_stats(v, n4, lane, cols, eps);
   ln_store(v, st, gamma, beta, n4, lane, o32 ? o32 + (size_t)row * cols : nullptr,
-           o16 ? o16 + (size_t)row * cols : nullptr);
+           o16 ? o16 + (size_t)row * cols : nullptr, dt);
 }
 
 // ---- BertEmbeddings from ids: word[id] + type[tt] + pos[s] -> LN
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ type, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int rows, int S,
                                                        int cols, int vocab, int type_vocab,
-                                                       float* __restrict__ o32, bf16_t* __restrict__ o16) {
+                                                       float* __restrict__ o32, bf16_t* __restrict__ o16, int dt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
     }
   }
   const RowStats st = row_stats(v, n4, lane, cols, eps);
-  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols);
+  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols, dt);
 }
 
 // ---- cross-encoder embeddings from inputs_embeds: x + type[0] + pos[t] -> LN  (row = pair*T + t)
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
                                                           const float* __restrict__ type0,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, int rows, int T,
-                                                          int cols, float* __restrict__ o32, bf16_t* __restrict__ o16) {
+                                                          int cols, float* __restrict__ o32, bf16_t* __restrict__ o16,
+                                                          int dt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
     }
   }
   const RowStats st = row_stats(v, n4, lane, cols, eps);
-  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols);
+  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols, dt);
 }
 
 // ---- late-interaction rows: (x * mask) -> L2 normalise (F.normalize eps 1e-12) -> bf16, scattered
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
 __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids,
                                                            int ids_stride, int n_pairs, int rows_per_batch, int D,
                                                            int T, int t_off, int pair_off, int bdiv,
-                                                           int src_batch_off, bf16_t* __restrict__ dst) {
+                                                           int src_batch_off, bf16_t* __restrict__ dst, int dt) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_pairs * rows_per_batch) return;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restri
   for (int i = 0; i < MAX_V4; ++i) {
     const int c4 = lane + 64 * i;
     if (c4 < n4)
-      ((uint2*)d)[c4] = make_uint2(pack2bf(v[i].x / nrm, v[i].y / nrm), pack2bf(v[i].z / nrm, v[i].w / nrm));
+      ((uint2*)d)[c4] = make_uint2(pack2rt(v[i].x / nrm, v[i].y / nrm, dt), pack2rt(v[i].z / nrm, v[i].w / nrm, dt));
   }
 }
 
@@ -180,11 +181,11 @@ __global__ void key_bias_kernel(const int64_t* __restrict__ ids, const int64_t* 
   }
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4) {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4, int dt) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const float4 a = ((const float4*)x)[i];
-  ((uint2*)y)[i] = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
+  ((uint2*)y)[i] = make_uint2(pack2rt(a.x, a.y, dt), pack2rt(a.z, a.w, dt));
 }
 
 // rows (dst_batch, j<rows_take) <- src row (dst_batch + off)/bdiv - src_off : generic 16-byte row gather/broadcast
@@ -228,38 +229,38 @@ __global__ __launch_bounds__(256) void cls_heads_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
-                               float* out_f32, bf16_t* out_bf16, hipStream_t st) {
+                               float* out_f32, bf16_t* out_bf16, int dt, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
-                     out_f32, out_bf16);
+                     out_f32, out_bf16, dt);
   return hipGetLastError();
 }
 
 hipError_t rr_launch_embed_ln(const int64_t* ids, const int64_t* tts, const float* word, const float* pos,
                               const float* type, const float* gamma, const float* beta, float eps, int rows, int S,
-                              int cols, int vocab, int type_vocab, float* o32, bf16_t* o16, hipStream_t st) {
+                              int cols, int vocab, int type_vocab, float* o32, bf16_t* o16, int dt, hipStream_t st) {
   if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ids, tts, word, pos, type, gamma,
-                     beta, eps, rows, S, cols, vocab, type_vocab, o32, o16);
+                     beta, eps, rows, S, cols, vocab, type_vocab, o32, o16, dt);
   return hipGetLastError();
 }
 
 hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* type0, const float* gamma,
                                  const float* beta, float eps, int rows, int T, int cols, float* o32, bf16_t* o16,
-                                 hipStream_t st) {
+                                 int dt, hipStream_t st) {
   if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ce_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, pos, type0, gamma, beta, eps,
-                     rows, T, cols, o32, o16);
+                     rows, T, cols, o32, o16, dt);
   return hipGetLastError();
 }
 
 hipError_t rr_launch_li_normalize(const float* src, const int64_t* ids, int ids_stride, int n_pairs,
                                   int rows_per_batch, int D, int T, int t_off, int pair_off, int bdiv,
-                                  int src_batch_off, bf16_t* dst, hipStream_t st) {
+                                  int src_batch_off, bf16_t* dst, int dt, hipStream_t st) {
   if (n_pairs <= 0 || rows_per_batch <= 0 || (D & 3) || D > 64 * 4 * MAX_V4 || bdiv <= 0) return hipErrorInvalidValue;
   const int rows = n_pairs * rows_per_batch;
   hipLaunchKernelGGL(li_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, src, ids, ids_stride, n_pairs,
-                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst);
+                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst, dt);
   return hipGetLastError();
 }
 
@@ -271,10 +272,10 @@ hipError_t rr_launch_key_bias(const int64_t* ids, const int64_t* am, int n, int 
   return hipGetLastError();
 }
 
-hipError_t rr_launch_f32_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
+hipError_t rr_launch_f32_to_bf16(const float* x, bf16_t* y, size_t n, int dt, hipStream_t st) {
   if (n & 3) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, n4);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, n4, dt);
   return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
 
 // Variant S ("simple"): 16x16x32 MFMA, tile barrier at the top of each K-tile, fragment reads scheduled by the
 // compiler inside the tile.
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool LDS_EPI>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, bool LDS_EPI, int DT>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __restrict__ A, int lda,
                                                              const bf16_t* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias,
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+          acc[nt][mt] = mfma16<DT>(wf[nt], af[mt], acc[nt][mt]);
     }
   }
   stamp(stamps, 2);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
         if constexpr (F32_OUT) acc[nt][mt] = f32x4{v0, v1, v2, v3};
-        else pk[nt][mt] = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        else pk[nt][mt] = make_uint2(pack2<DT>(v0, v1), pack2<DT>(v2, v3));
       }
     }
     __builtin_amdgcn_s_barrier();                             // all MFMA-phase LDS reads are complete
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       if (F32_OUT) {
         *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
       } else {
-        *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2<DT>(v0, v1), pack2<DT>(v2, v3));
       }
     }
   }
@@ -636,7 +636,7 @@ hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
 }
 
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool LDS_EPI = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool LDS_EPI = false, int DT = 0>
 hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
                       int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
@@ -651,7 +651,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   unsigned long long* stamps = g_stamps;
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
-    auto kern = PIPE ? gemm_kernel_p<BM, BN, WM, WN, STAGES, E> : gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI>;                                                       \
+    auto kern = PIPE ? gemm_kernel_p<BM, BN, WM, WN, STAGES, E> : gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI, DT>;                                                       \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -697,7 +697,8 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
 
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
-                          int epilogue, hipStream_t st) {
+                          int epilogue, int dt, hipStream_t st) {
+  if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
   if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;
@@ -714,6 +715,14 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     // the direct form's store issue (measured, tools/bench_gemm.py --stamps).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     v = tiles256 >= 512 ? ((epilogue == EPI_BIAS_GELU_BF16 || (N & 7)) ? 2 : 10) : 0;
+  }
+  if (dt == 1) {   // fp16 operands: the production configurations only
+    switch (v) {
+      case 0: return launch_cfg<128, 128, 2, 2, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      case 2: return launch_cfg<256, 256, 2, 4, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      default: return hipErrorInvalidValue;
+    }
   }
 #define RR_CFG(BM_, BN_, WM_, WN_, ST_, P_) \
   return launch_cfg<BM_, BN_, WM_, WN_, ST_, P_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st)

@@ -17,13 +17,13 @@
 
 // launchers implemented in the other translation units
 hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*,
-                              const float*, float, int, int, int, int, int, float*, bf16_t*, hipStream_t);
+                              const float*, float, int, int, int, int, int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
-                                 int, float*, bf16_t*, hipStream_t);
+                                 int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
-                                  hipStream_t);
+                                  int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
-hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, hipStream_t);
+hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_cls_heads(const float*, int, int, int, const float*, const float*, const float*, const float*,
                                float*, float*, hipStream_t);
@@ -38,6 +38,26 @@ uint16_t host_f2bf(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
+}
+uint16_t host_f2h(float f) {      // IEEE binary16, round-to-nearest-even
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);              // NaN
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);             // >= 65520 -> inf
+  if (u < 0x33000001u) return (uint16_t)sign;                           // < 2^-25 -> 0
+  if (u < 0x38800000u) {                                                // subnormal half
+    const int e = (int)(u >> 23);
+    uint32_t m = (u & 0x7fffffu) | 0x800000u;
+    const int shift = 126 - e;                                          // 14 .. 24
+    const uint32_t half = m >> shift, rem = m & ((1u << shift) - 1), mid = 1u << (shift - 1);
+    return (uint16_t)(sign | (half + ((rem > mid) || (rem == mid && (half & 1)))));
+  }
+  uint32_t h = ((u - 0x38000000u) >> 13);
+  const uint32_t rem = u & 0x1fffu;
+  h += (rem > 0x1000u) || (rem == 0x1000u && (h & 1));
+  return (uint16_t)(sign | h);
 }
 float host_bf2f(uint16_t b) {
   uint32_t u = ((uint32_t)b) << 16;
@@ -78,6 +98,7 @@ struct ProfEvent {
 
 struct rr_model {
   rr_config cfg;
+  int dt = 0;                       // 16-bit operand dtype: 0 bf16, 1 fp16 (cfg.compute_dtype)
   std::string err;
   bool finalized = false;
   std::map<std::string, std::vector<int64_t>> required;   // name -> expected shape
@@ -246,9 +267,10 @@ int up_f32(rr_model* m, const std::vector<float>& v, float** out) {
   RR_HIP(m, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
   return RR_OK;
 }
-int up_bf16(rr_model* m, const std::vector<float>& v, bf16_t** out) {
+int up_bf16(rr_model* m, const std::vector<float>& v, bf16_t** out) {   // 16-bit MFMA operand in the model's compute dtype
   std::vector<uint16_t> t(v.size());
-  for (size_t i = 0; i < v.size(); ++i) t[i] = host_f2bf(v[i]);
+  if (m->dt) for (size_t i = 0; i < v.size(); ++i) t[i] = host_f2h(v[i]);
+  else for (size_t i = 0; i < v.size(); ++i) t[i] = host_f2bf(v[i]);
   int rc = dev_alloc(m, (void**)out, t.size() * 2);
   if (rc) return rc;
   RR_HIP(m, hipMemcpy(*out, t.data(), t.size() * 2, hipMemcpyHostToDevice));
@@ -397,7 +419,7 @@ double gemm_bytes(double M, double N, double K, double out_elt) { return 2.0 * (
 
 #define RR_GEMM(m, st, A, lda, W, bias, resid, ldr, C, ldc, M, N, K, epi, outb)                         \
   RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, outb) + (((const void*)(resid) != nullptr) ? 4.0 * (M) * (N) : 0.0), \
-         rr_launch_gemm(A, lda, W, K, bias, resid, ldr, C, ldc, M, N, K, epi, st))
+         rr_launch_gemm(A, lda, W, K, bias, resid, ldr, C, ldc, M, N, K, epi, m->dt, st))
 
 // One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
@@ -406,14 +428,14 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
          rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
-                             Tseq, w.ctx, Hd, st));
+                             Tseq, w.ctx, Hd, m->dt, st));
   RR_GEMM(m, st, w.ctx, Hd, L.wo, L.bo, w.h32, Hd, w.pre, Hd, rows, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
   RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
-         rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, st));
+         rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
   RR_GEMM(m, st, w.h16, Hd, L.w1, L.b1, nullptr, 0, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
   RR_GEMM(m, st, w.mid, I, L.w2, L.b2, w.h32, Hd, w.pre, Hd, rows, Hd, I, EPI_BIAS_RESID_F32, 4.0);
   RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
-         rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, st));
+         rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
   return RR_OK;
 }
 
@@ -471,8 +493,10 @@ int rr_create(const rr_config* cfg, rr_handle* out) {
     return RR_ERR_NO_DEVICE;
   }
   if (hipSetDevice(c.device) != hipSuccess) return RR_ERR_HIP;
+  if (c.compute_dtype != 0 && c.compute_dtype != 1) return bad("compute_dtype must be 0 (bf16) or 1 (fp16)");
   rr_model* m = new rr_model();
   m->cfg = c;
+  m->dt = c.compute_dtype;
   build_required(m);
   *out = m;
   return RR_OK;
@@ -655,7 +679,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   // ---- text encoder (FLMRTextModel = BertModel)
   RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * R * Hd,
          rr_launch_embed_ln(ids, tts, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps, R, S, Hd, c.vocab_size,
-                            c.type_vocab, w.h32, w.h16, st));
+                            c.type_vocab, w.h32, w.h16, m->dt, st));
   for (int l = 0; l < c.layers; ++l)
     RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w));
   if (m->debug) {
@@ -670,22 +694,22 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   // ---- 768 -> 128 projection (no bias), mask, L2 normalise -> li16[:, :S]
   RR_GEMM(m, st, w.h16, Hd, m->w_li, nullptr, nullptr, 0, w.li32, D, R, D, Hd, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * R * D + 8.0 * R,
-         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, st));
+         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, st));
 
   if (vision) {
     const int np = c.n_patches, PL = c.prefix_len, Vh = c.vision_hidden, mid = D * PL / 2, outd = D * PL;
     const float* cls = image_cls + (size_t)q_lo * Vh;
     const float* pat = image_patches + (size_t)q_lo * np * Vh;
     // prefix MLP (per query): Linear -> Tanh -> Linear -> view [PL, D]
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * Vh, rr_launch_f32_to_bf16(cls, w.cls16, (size_t)nq * Vh, st));
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * Vh, rr_launch_f32_to_bf16(cls, w.cls16, (size_t)nq * Vh, m->dt, st));
     RR_GEMM(m, st, w.cls16, Vh, m->w_vp0, m->b_vp0, nullptr, 0, w.vp_mid16, mid, nq, mid, Vh, EPI_BIAS_TANH_BF16, 2.0);
     RR_GEMM(m, st, w.vp_mid16, mid, m->w_vp2, m->b_vp2, nullptr, 0, w.vp_out32, outd, nq, outd, mid, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * PL * D,
-           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, st));
+           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, m->dt, st));
     // mapping network: input linear + self-attention block depend on the image only => per query
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, st));
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, m->dt, st));
     RR_GEMM(m, st, w.pat16, Vh, m->w_min, m->b_min, nullptr, 0, w.t32, Hd, nq * np, Hd, Vh, EPI_BIAS_F32, 4.0);
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Hd, rr_launch_f32_to_bf16(w.t32, w.t16, (size_t)nq * np * Hd, st));
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Hd, rr_launch_f32_to_bf16(w.t32, w.t16, (size_t)nq * np * Hd, m->dt, st));
     const int ca = S < c.cross_attn_len ? S : c.cross_attn_len;
     // pair-specific text states the cross-attention reads: first `ca` rows of every pair (rerank_model.py:438-442)
     RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * ca * Hd,
@@ -700,16 +724,16 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
       RR_GEMM(m, st, tin16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.vqkv, 3 * Hd, bt * np, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * bt * (double)np * np * Hd, 8.0 * bt * np * Hd,
              rr_launch_attention(w.vqkv, 3 * Hd, 1, 0, w.vqkv + Hd, w.vqkv + 2 * Hd, 3 * Hd, nullptr, bt, c.heads, np, np,
-                                 w.vctx, Hd, st));
+                                 w.vctx, Hd, m->dt, st));
       RR_GEMM(m, st, w.vctx, Hd, L.wo, L.bo, tin32, Hd, w.vpre, Hd, bt * np, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * bt * np * Hd,
-             rr_launch_layernorm(w.vpre, L.ln1g, L.ln1b, c.ln_eps, bt * np, Hd, w.a32, w.a16, st));
+             rr_launch_layernorm(w.vpre, L.ln1g, L.ln1b, c.ln_eps, bt * np, Hd, w.a32, w.a16, m->dt, st));
       // cross-attention: queries from `a`, keys/values from the pair's first `ca` text states
       RR_GEMM(m, st, w.a16, Hd, L.wq_c, L.bq_c, nullptr, 0, w.q_c, Hd, bt * np, Hd, Hd, EPI_BIAS_BF16, 2.0);
       RR_GEMM(m, st, w.enc16, Hd, L.wkv_c, L.bkv_c, nullptr, 0, w.kv_c, 2 * Hd, n * ca, 2 * Hd, Hd, EPI_BIAS_BF16, 2.0);
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)np * ca * Hd, 2.0 * n * (2.0 * np + 2.0 * ca) * Hd,
              rr_launch_attention(w.q_c, Hd, per_query ? K : 1, per_query ? pair_begin - q_lo * K : 0, w.kv_c,
-                                 w.kv_c + Hd, 2 * Hd, nullptr, n, c.heads, np, ca, w.cctx, Hd, st));
+                                 w.kv_c + Hd, 2 * Hd, nullptr, n, c.heads, np, ca, w.cctx, Hd, m->dt, st));
       const float* resid = w.a32;
       if (per_query) {   // broadcast the per-query residual to the pairs
         RR_RUN(m, st, RR_K_TAIL, 0.0, 8.0 * n * np * Hd,
@@ -718,11 +742,11 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
       }
       RR_GEMM(m, st, w.cctx, Hd, L.wo_c, L.bo_c, resid, Hd, w.cpre, Hd, n * np, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * np * Hd,
-             rr_launch_layernorm(w.cpre, L.lncg, L.lncb, c.ln_eps, n * np, Hd, w.c32, w.c16, st));
+             rr_launch_layernorm(w.cpre, L.lncg, L.lncb, c.ln_eps, n * np, Hd, w.c32, w.c16, m->dt, st));
       RR_GEMM(m, st, w.c16, Hd, L.w1, L.b1, nullptr, 0, w.vmid, I, n * np, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
       RR_GEMM(m, st, w.vmid, I, L.w2, L.b2, w.c32, Hd, w.cpre, Hd, n * np, Hd, I, EPI_BIAS_RESID_F32, 4.0);
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * np * Hd,
-             rr_launch_layernorm(w.cpre, L.ln2g, L.ln2b, c.ln_eps, n * np, Hd, w.m32, w.m16, st));
+             rr_launch_layernorm(w.cpre, L.ln2g, L.ln2b, c.ln_eps, n * np, Hd, w.m32, w.m16, m->dt, st));
       tin32 = w.m32;
       tin16 = w.m16;
     }
@@ -732,7 +756,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
     }
     RR_GEMM(m, st, w.m16, Hd, m->w_mout, m->b_mout, nullptr, 0, w.mo32, D, n * np, D, Hd, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * np * D,
-           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, st));
+           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, m->dt, st));
   }
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)RT * D;
@@ -740,7 +764,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   // ---- cross encoder: Linear(D -> Hc) -> embeddings(inputs_embeds) -> Lc layers -> CLS -> heads
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
-         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, st));
+         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
   for (int l = 0; l < c.ce_layers; ++l)
     RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w));
   m->tap_ce = w.h32;
@@ -786,7 +810,7 @@ int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t ma
     if (!h->tap_li || (int64_t)h->tap_li_elems > max_elems) return fail(h, RR_ERR_BAD_SHAPE, "no tap / buffer too small");
     std::vector<uint16_t> t(h->tap_li_elems);
     if (hipMemcpy(t.data(), h->tap_li, t.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return RR_ERR_HIP;
-    for (size_t i = 0; i < t.size(); ++i) host_out[i] = host_bf2f(t[i]);
+    for (size_t i = 0; i < t.size(); ++i) host_out[i] = h->dt ? host_h2f(t[i]) : host_bf2f(t[i]);
     return (int64_t)t.size();
   }
   return fail(h, RR_ERR_BAD_ARG, "unknown tap %s", name);
@@ -821,19 +845,26 @@ int rr_get_profile(rr_handle h, rr_profile* out, int reset) {
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------
+static int g_op_dt = 0;   // operand dtype used by the stand-alone rr_op_* entry points (rr_set_op_dtype)
+int rr_set_op_dtype(int dt) {
+  if (dt != 0 && dt != 1) return RR_ERR_BAD_ARG;
+  g_op_dt = dt;
+  return RR_OK;
+}
+
 int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue,
                     void* out, void* hip_stream) {
   if (!A || !W || !out) return RR_ERR_BAD_ARG;
   if (epilogue < 0 || epilogue > 3) return RR_ERR_BAD_ARG;
   const int epi_map[4] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32, EPI_BIAS_TANH_BF16};
-  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, nullptr, 0, out, N, M, N, Kd, epi_map[epilogue], (hipStream_t)hip_stream);
+  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, nullptr, 0, out, N, M, N, Kd, epi_map[epilogue], g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
 int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N,
                          int Kd, float* out, void* hip_stream) {
   if (!A || !W || !out || !resid) return RR_ERR_BAD_ARG;
-  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, resid, N, out, N, M, N, Kd, EPI_BIAS_RESID_F32, (hipStream_t)hip_stream);
+  hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, resid, N, out, N, M, N, Kd, EPI_BIAS_RESID_F32, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
@@ -842,14 +873,14 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
                          int out_stride, void* hip_stream) {
   if (!q || !k || !v || !out) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_attention(q, q_stride, q_batch_div, 0, k, v, kv_stride, key_bias, B, heads, Tq, Tk, out,
-                                     out_stride, (hipStream_t)hip_stream);
+                                     out_stride, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream) {
   if (!x || !gamma || !beta || (!out_f32 && !out_bf16)) return RR_ERR_BAD_ARG;
-  hipError_t e = rr_launch_layernorm(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, (hipStream_t)hip_stream);
+  hipError_t e = rr_launch_layernorm(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 

@@ -26,6 +26,32 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));   // one v_cvt_pk_bf16_f32
 }
 
+// ---- 16-bit operand type of the MFMA path: DT 0 = bf16 (default, what the reference's bf16-mixed runs use),
+// DT 1 = fp16 (same MFMA rate, 3 more mantissa bits; buffers are the same uint16 carriers).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (DT == 0) {
+    return pack2bf(lo, hi);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    const f32x2_ v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_));   // round-to-nearest-even
+  }
+}
+__device__ __forceinline__ uint32_t pack2rt(float lo, float hi, int dt) { return dt ? pack2<1>(lo, hi) : pack2<0>(lo, hi); }
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (DT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (DT == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // LDS byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64 x bf16] tile image
 // (128-byte rows).  XOR with (row>>1)&7 keeps every ds_read_b128 lane group (16 rows of one
 // chunk column, cdna_hip_programming.md §2 / T2) on 16 distinct 16-byte slots of the
@@ -56,15 +82,15 @@ enum GemmEpilogue {
 // resid [M,N] f32 (row stride ldr, EPI 4) ; C row stride ldc (elements of its type).
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
-                          int epilogue, hipStream_t st);
+                          int epilogue, int dt, hipStream_t st);
 
 // Multi-head attention, head dim 64.  q rows: q + (bq*Tq + t)*q_stride + head*64, where
 // bq = (b + q_batch_off) / q_batch_div;  k,v rows: (b*Tk + t)*kv_stride + head*64;  key_bias [B,Tk] f32 additive
 // (0 valid, -1e30 masked) or null;  out rows: (b*Tq + t)*out_stride + head*64 (bf16).
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B,
-                               int heads, int Tq, int Tk, bf16_t* out, int out_stride,
+                               int heads, int Tq, int Tk, bf16_t* out, int out_stride, int dt,
                                hipStream_t st);
 
 hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
-                               int rows, int cols, float* out_f32, bf16_t* out_bf16, hipStream_t st);
+                               int rows, int cols, float* out_f32, bf16_t* out_bf16, int dt, hipStream_t st);

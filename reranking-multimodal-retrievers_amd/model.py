@@ -59,7 +59,8 @@ def make_arch(reranker_config=None, **overrides) -> dict:
              ce_max_pos=_get(reranker_config, "cross_encoder_max_position_embeddings", 750),
              loss_fn=_get(reranker_config, "loss_fn", "BCE"),
              pos_weight=_get(reranker_config, "pos_weight", None),
-             has_vision=1)
+             has_vision=1,
+             compute_dtype=_get(reranker_config, "compute_dtype", "bf16"))   # "bf16" | "fp16" MFMA operands
     a.update(_get(reranker_config, "arch", None) or {})
     a.update(overrides)
     return a
@@ -153,6 +154,10 @@ class RerankEngine:
             raise ValueError(f"Unknown loss function {arch['loss_fn']}")        # utils.py:222-223
         c.loss_kind = L.LOSS_KINDS[arch["loss_fn"]]
         c.pos_weight = float("nan") if arch.get("pos_weight") is None else float(arch["pos_weight"])
+        cd = arch.get("compute_dtype", "bf16")
+        if cd not in L.COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(L.COMPUTE_DTYPES)}, got {cd!r}")
+        c.compute_dtype = L.COMPUTE_DTYPES[cd]
         c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         L.check(self.lib.rr_create(C.byref(c), C.byref(h)), None, "rr_create")

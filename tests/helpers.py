@@ -35,11 +35,11 @@ def golden_inputs(g):
     return ids, am, tt, img
 
 
-def arch_from_cfg(cfg: O.OracleConfig, vision: bool) -> dict:
+def arch_from_cfg(cfg: O.OracleConfig, vision: bool, compute_dtype: str = "bf16") -> dict:
     return dict(vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
                 intermediate=cfg.intermediate, max_pos=cfg.max_pos, type_vocab=cfg.type_vocab, ln_eps=cfg.ln_eps,
                 li_dim=cfg.li_dim, ce_hidden=cfg.ce_hidden, ce_layers=cfg.ce_layers, ce_heads=cfg.ce_heads,
                 ce_intermediate=cfg.ce_intermediate, ce_max_pos=cfg.ce_max_pos, has_vision=int(vision),
                 vision_hidden=cfg.vision_hidden, prefix_len=cfg.prefix_len, n_patches=cfg.n_patches,
                 map_layers=cfg.map_layers, cross_attn_len=cfg.cross_attn_len, loss_fn=cfg.loss_fn,
-                pos_weight=cfg.pos_weight)
+                pos_weight=cfg.pos_weight, compute_dtype=compute_dtype)

@@ -200,3 +200,46 @@ def test_layernorm(lib, rows, cols):
     ref = torch.nn.functional.layer_norm(x, (cols,), gamma, beta, 1e-12)
     assert torch.allclose(o32, ref, atol=2e-6, rtol=1e-5)
     assert torch.equal(o16, o32.bfloat16())
+
+
+def test_fp16_operand_ops(lib):
+    """The same GEMM / attention kernels instantiated for fp16 operands (compute_dtype "fp16")."""
+    assert lib.rr_set_op_dtype(1) == 0
+    try:
+        g = torch.Generator().manual_seed(11)
+        M, N, K = 300, 768, 768
+        A = (torch.randn(M, K, generator=g) * 0.7).half().cuda()
+        W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+        b = torch.randn(N, generator=g).cuda()
+        out = torch.empty(M, N, device="cuda")
+        assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, 2, out.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.allclose(out, A.float() @ W.float().t() + b, atol=3e-4, rtol=1e-4)
+        outh = torch.empty(M, N, device="cuda", dtype=torch.float16)
+        assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, 1, outh.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        ref = _gelu(A.float() @ W.float().t() + b)
+        assert ((outh.float() - ref).abs() <= 2e-3 * (1 + ref.abs())).all()
+        B, heads, T = 2, 12, 200
+        H = heads * 64
+        q = (torch.randn(B, T, H, generator=g) * 0.5).half().cuda()
+        k = torch.randn(B, T, H, generator=g).half().cuda()
+        v = torch.randn(B, T, H, generator=g).half().cuda()
+        keep = torch.rand(B, T, generator=g) > 0.3
+        keep[:, 0] = True
+        bias = torch.where(keep, 0.0, -1e30).float().cuda()
+        o = torch.empty(B, T, H, dtype=torch.float16, device="cuda")
+        assert lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), H, H, bias.data_ptr(), B, heads, T, T,
+                                        1, o.data_ptr(), H, _stream()) == 0
+        torch.cuda.synchronize()
+        ref = _attn_ref(q, k, v, bias, heads)
+        assert (o.float() - ref).abs().max().item() < 3e-3
+        x = torch.randn(9, 768, generator=g).cuda()
+        gm, bt = torch.ones(768).cuda(), torch.zeros(768).cuda()
+        o32, o16 = torch.empty_like(x), torch.empty(9, 768, dtype=torch.float16, device="cuda")
+        assert lib.rr_op_layernorm(x.data_ptr(), gm.data_ptr(), bt.data_ptr(), 1e-12, 9, 768, o32.data_ptr(),
+                                   o16.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(o16, o32.half())
+    finally:
+        lib.rr_set_op_dtype(0)
