@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--text-only", action="store_true")
     ap.add_argument("--regime", default="full", choices=["full", "realistic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--cpu-pairs", type=int, default=64)
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit MFMA operand type of the timed run (north_star: bf16)")
