@@ -85,8 +85,17 @@ typedef struct rr_config {
                                  1 = fp16 (same MFMA rate, 3 more mantissa bits: logits within 1e-3 of the fp32
                                  forward; range +-65504 is ample for BERT activations, accumulation/residual/
                                  LayerNorm/softmax stay fp32 in both modes) */
-  int32_t reserved[6];
+  int32_t model_kind;         /* rr_model_kind: which reference reranker class the handle stands for */
+  int32_t reserved[5];
 } rr_config;
+
+/* reranker families */
+typedef enum rr_model_kind {
+  RR_MODEL_FULL_CONTEXT = 0,  /* FullContextRerankModel (monoBERT / monoPreFLMR), rerank_model.py:515-591  -> rr_forward */
+  RR_MODEL_INTERACTION = 1,   /* InteractionRerankModel, interaction_type NORMAL (ModPreFLMR-BERT),
+                                 interaction_rerank_model.py:110-166                          -> rr_forward_interaction */
+  RR_MODEL_MORES = 2          /* InteractionRerankModel, interaction_type MORES (ModPreFLMR-IB), mores_model.py:21-94 */
+} rr_model_kind;
 
 typedef struct rr_model* rr_handle;
 
@@ -155,6 +164,16 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
                int Bq, int K, int S, const float* labels, int pair_begin, int pair_end,
                float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
                int32_t* order_out, void* hip_stream);
+
+/* rr_forward_interaction: the Interaction rerankers, fed by the frozen retriever's late-interaction outputs
+ * (Reranker_base_executor.py:877-885 builds the call).  All pointers DEVICE float32:
+ *   query_li [Bq, Lq, li_dim], context_li [N, Lc, li_dim], query_mask [Bq, Lq] and context_mask [N, Lc] (0/1).
+ * Outputs, labels, pair slice and head semantics are those of rr_forward.  `preflmr_scores` attention fusion is not
+ * supported (no reference config enables it; MORES raises NotImplementedError for it too, mores_model.py:72-73). */
+int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                           const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
+                           int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                           float* scores_out, int32_t* order_out, void* hip_stream);
 
 /* rr_head: scoring head + loss + top-K order over complete logits [Bq*K] (after the RCCL
  * all-gather of per-rank slices).  Same semantics as the tail of rr_forward. */

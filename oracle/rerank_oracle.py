@@ -364,6 +364,104 @@ def full_context_forward(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Ten
     return OracleOutput(loss=loss, logits=logits, taps=taps or {})
 
 
+def mores_layer(h: Tensor, doc: Tensor, w: Dict[str, Tensor], p: str, heads: int, eps: float, qry_mask: Tensor,
+                cross_mask: Tensor, mm=None) -> Tensor:
+    """`MORES_BertLayer.forward` (mores_model.py:21-57): cross-attention(query -> doc) FIRST, then self-attention
+    over the query tokens, then the FFN; each sub-block is dense + residual + LayerNorm (post-LN)."""
+    q = linear(h, w, p + ".crossattention.self.query", mm)
+    k = linear(doc, w, p + ".crossattention.self.key", mm)
+    v = linear(doc, w, p + ".crossattention.self.value", mm)
+    ctx = _MHA[-1](q, k, v, heads, cross_mask)
+    a = layer_norm(linear(ctx, w, p + ".crossattention.output.dense", mm) + h, w,
+                   p + ".crossattention.output.LayerNorm", eps)
+    q = linear(a, w, p + ".attention.self.query", mm)
+    k = linear(a, w, p + ".attention.self.key", mm)
+    v = linear(a, w, p + ".attention.self.value", mm)
+    ctx = _MHA[-1](q, k, v, heads, qry_mask)
+    b = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + a, w, p + ".attention.output.LayerNorm", eps)
+    inter = gelu_erf(linear(b, w, p + ".intermediate.dense", mm))
+    return layer_norm(linear(inter, w, p + ".output.dense", mm) + b, w, p + ".output.LayerNorm", eps)
+
+
+def interaction_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_li: Tensor, context_li: Tensor,
+                        query_mask: Tensor, context_mask: Tensor, K: int, labels: Optional[List[float]] = None,
+                        mores: bool = False, mm=None, want_taps: bool = False) -> OracleOutput:
+    """`InteractionRerankModel.forward` (interaction_rerank_model.py:110-166) without attention fusion.
+    query_li [Bq,Lq,D], context_li [N,Lc,D], masks 0/1 [Bq,Lq] / [N,Lc]."""
+    Bq = query_li.shape[0]
+    N = Bq * K
+    assert N == context_li.shape[0], f"{query_li.shape}, {context_li.shape}, {K - 1}"          # :123
+    q = query_li.repeat_interleave(K, dim=0)                                                       # :128
+    qm = query_mask.to(torch.float32).repeat_interleave(K, dim=0)                                  # :129
+    cm = context_mask.to(torch.float32)
+    taps = {} if want_taps else None
+    if mores:                                                                                       # :147-156
+        h = linear(q, w, "cross_encoder_input_mapping", mm)
+        doc = linear(context_li.to(torch.float32), w, "cross_encoder_input_mapping", mm)
+        qb, cb = extended_mask(qm), extended_mask(cm)                                               # mores_model.py:75-76
+        for i in range(cfg.ce_layers):
+            h = mores_layer(h, doc, w, f"reranker.interaction_module.{i}", cfg.ce_heads, cfg.ln_eps, qb, cb, mm)
+        cls = h[:, 0]                                                                               # mores_model.py:88
+        l1, l2 = linear(cls, w, "reranker.classifier1"), linear(cls, w, "reranker.classifier2")
+    else:                                                                                           # :157-161
+        x = linear(torch.cat((q, context_li), dim=1), w, "cross_encoder_input_mapping", mm)
+        l1, l2 = cross_encoder(cfg, w, x, torch.cat((qm, cm), dim=1), None, mm, taps)
+    logits, lab = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)                     # :163
+    loss = loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)                                     # :164
+    if cfg.loss_fn == "2H_BCE":      # the reference returns both columns here (:165); ranking uses column 1 everywhere else
+        logits = logits[:, 1].unsqueeze(1)
+    return OracleOutput(loss=loss, logits=logits, taps=taps or {})
+
+
+def interaction_weight_spec(cfg: OracleConfig, mores: bool) -> List[Tuple[str, Tuple[int, ...], str]]:
+    Hc, Ic, D = cfg.ce_hidden, cfg.ce_intermediate, cfg.li_dim
+    s: List[Tuple[str, Tuple[int, ...], str]] = [("cross_encoder_input_mapping.weight", (Hc, D), "w"),
+                                                  ("cross_encoder_input_mapping.bias", (Hc,), "b")]
+    if mores:
+        for i in range(cfg.ce_layers):
+            s += _layer_shapes(f"reranker.interaction_module.{i}", Hc, Ic, True)
+    else:
+        p = "reranker.bert_model"
+        s += [(f"{p}.embeddings.position_embeddings.weight", (cfg.ce_max_pos, Hc), "e"),
+              (f"{p}.embeddings.token_type_embeddings.weight", (cfg.type_vocab, Hc), "e"),
+              (f"{p}.embeddings.LayerNorm.weight", (Hc,), "g"), (f"{p}.embeddings.LayerNorm.bias", (Hc,), "b")]
+        for i in range(cfg.ce_layers):
+            s += _layer_shapes(f"{p}.encoder.layer.{i}", Hc, Ic, False)
+    s += [("reranker.classifier1.weight", (1, Hc), "w"), ("reranker.classifier1.bias", (1,), "b"),
+          ("reranker.classifier2.weight", (1, Hc), "w"), ("reranker.classifier2.bias", (1,), "b")]
+    return s
+
+
+def make_interaction_weights(cfg: OracleConfig, mores: bool, seed: int = 0, hf_init: bool = False) -> Dict[str, Tensor]:
+    w: Dict[str, Tensor] = {}
+    for idx, (name, shape, kind) in enumerate(interaction_weight_spec(cfg, mores)):
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        if kind in ("w", "e"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif kind == "g":
+            t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.zeros(shape) if hf_init else 0.05 * torch.randn(shape, generator=g)
+        w[name] = t
+    return w
+
+
+def make_interaction_inputs(cfg: OracleConfig, Bq: int, K: int, Lq: int, Lc: int, seed: int = 2022):
+    """Retriever-shaped inputs: unit-norm token embeddings, zero rows where masked (modeling_flmr.py:1365-1370,
+    1551-1552), ragged context lengths."""
+    g = torch.Generator().manual_seed(seed)
+    N = Bq * K
+    q = F.normalize(torch.randn(Bq, Lq, cfg.li_dim, generator=g), dim=-1)
+    c = F.normalize(torch.randn(N, Lc, cfg.li_dim, generator=g), dim=-1)
+    qm = torch.ones(Bq, Lq)
+    qm[:, max(2, Lq // 3): max(3, Lq // 2)] = 0                     # some masked query tokens in the middle
+    cm = torch.zeros(N, Lc)
+    for n in range(N):
+        L = int(torch.randint(max(2, Lc // 4), Lc + 1, (1,), generator=g))
+        cm[n, :L] = 1
+    return q * qm[..., None], c * cm[..., None], qm, cm
+
+
 # --------------------------------------------------------------------------- rank + metric
 def rank_descending_stable(scores: Sequence[float]) -> List[int]:
     """`sorted(zip(docs, logits), key=score, reverse=True)`

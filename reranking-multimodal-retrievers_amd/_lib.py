@@ -19,6 +19,7 @@ RR_ERR_HIP, RR_ERR_OOM, RR_ERR_MISSING_WEIGHT, RR_ERR_NO_DEVICE = -5, -6, -7, -8
 RR_F32, RR_BF16, RR_F16 = 0, 1, 2
 LOSS_KINDS = {"BCE": 0, "2H_BCE": 1, "negative_sampling": 2}
 COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
+MODEL_KINDS = {"full_context": 0, "interaction": 1, "mores": 2}
 KERNEL_CLASSES = ["gemm", "attention", "layernorm", "embed", "tail", "head"]
 
 
@@ -30,7 +31,7 @@ class RRConfig(C.Structure):
                                          "has_vision", "vision_hidden", "prefix_len", "n_patches", "map_layers",
                                          "cross_attn_len", "loss_kind")] + \
                [("pos_weight", C.c_float), ("device", C.c_int32), ("compute_dtype", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("model_kind", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class RRProfile(C.Structure):
@@ -57,6 +58,8 @@ _SIGS = {
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
     "rr_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                              _P, _P, _P, _P, _P, _P]),
+    "rr_forward_interaction": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                         _P, _P, _P, _P, _P, _P]),
     "rr_head": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "rr_debug_read": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "rr_set_debug": (C.c_int, [_P, C.c_int]),

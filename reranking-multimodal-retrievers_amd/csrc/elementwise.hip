@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
 __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restrict__ src, const int64_t* __restrict__ ids,
                                                            int ids_stride, int n_pairs, int rows_per_batch, int D,
                                                            int T, int t_off, int pair_off, int bdiv,
-                                                           int src_batch_off, bf16_t* __restrict__ dst, int dt) {
+                                                           int src_batch_off, bf16_t* __restrict__ dst, int dt,
+                                                           int normalize) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_pairs * rows_per_batch) return;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restri
       q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
     }
   }
-  const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+  const float nrm = normalize ? fmaxf(sqrtf(wave_sum(q)), 1e-12f) : 1.0f;   // 0: plain convert/concat
   bf16_t* d = dst + ((size_t)p * T + t_off + j) * D;
 #pragma unroll
   for (int i = 0; i < MAX_V4; ++i) {
@@ -179,6 +180,26 @@ __global__ void key_bias_kernel(const int64_t* __restrict__ ids, const int64_t* 
   } else {
     ce_bias[i] = 0.f;
   }
+}
+
+// ---- interaction rerankers: key bias over the concatenated [query tokens | context tokens] sequence from the
+// retriever's 0/1 masks (interaction_rerank_model.py:153); also the two separate biases MORES needs.
+__global__ void interaction_bias_kernel(const float* __restrict__ qmask, const float* __restrict__ cmask, int n, int Lq,
+                                        int Lc, int pair_off, int K, float* __restrict__ cat_bias,
+                                        float* __restrict__ q_bias, float* __restrict__ c_bias) {
+  const int T = Lq + Lc;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * T) return;
+  const int p = i / T, t = i - p * T;
+  float b;
+  if (t < Lq) {
+    b = qmask[(size_t)((p + pair_off) / K) * Lq + t] != 0.f ? 0.f : -1e30f;
+    if (q_bias) q_bias[(size_t)p * Lq + t] = b;
+  } else {
+    b = cmask[(size_t)p * Lc + (t - Lq)] != 0.f ? 0.f : -1e30f;
+    if (c_bias) c_bias[(size_t)p * Lc + (t - Lq)] = b;
+  }
+  if (cat_bias) cat_bias[i] = b;
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4, int dt) {
@@ -256,11 +277,11 @@ hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* 
 
 hipError_t rr_launch_li_normalize(const float* src, const int64_t* ids, int ids_stride, int n_pairs,
                                   int rows_per_batch, int D, int T, int t_off, int pair_off, int bdiv,
-                                  int src_batch_off, bf16_t* dst, int dt, hipStream_t st) {
+                                  int src_batch_off, bf16_t* dst, int dt, int normalize, hipStream_t st) {
   if (n_pairs <= 0 || rows_per_batch <= 0 || (D & 3) || D > 64 * 4 * MAX_V4 || bdiv <= 0) return hipErrorInvalidValue;
   const int rows = n_pairs * rows_per_batch;
   hipLaunchKernelGGL(li_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, src, ids, ids_stride, n_pairs,
-                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst, dt);
+                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst, dt, normalize);
   return hipGetLastError();
 }
 
@@ -269,6 +290,14 @@ hipError_t rr_launch_key_bias(const int64_t* ids, const int64_t* am, int n, int 
   const int total = n * T;
   hipLaunchKernelGGL(key_bias_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ids, am, n, S, T, text_bias,
                      ce_bias);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_interaction_bias(const float* qmask, const float* cmask, int n, int Lq, int Lc, int pair_off, int K,
+                                      float* cat_bias, float* q_bias, float* c_bias, hipStream_t st) {
+  const int total = n * (Lq + Lc);
+  hipLaunchKernelGGL(interaction_bias_kernel, dim3((total + 255) / 256), dim3(256), 0, st, qmask, cmask, n, Lq, Lc,
+                     pair_off, K, cat_bias, q_bias, c_bias);
   return hipGetLastError();
 }
 

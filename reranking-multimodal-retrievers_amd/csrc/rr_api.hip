@@ -21,7 +21,9 @@ hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, cons
 hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
                                  int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
-                                  int, hipStream_t);
+                                  int, int, hipStream_t);
+hipError_t rr_launch_interaction_bias(const float*, const float*, int, int, int, int, int, float*, float*, float*,
+                                      hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -219,6 +221,28 @@ void req_layer(rr_model* m, const std::string& p, int H, int I, bool cross) {
 void build_required(rr_model* m) {
   const rr_config& c = m->cfg;
   const int H = c.hidden, I = c.intermediate, D = c.li_dim;
+  if (c.model_kind != RR_MODEL_FULL_CONTEXT) {
+    // InteractionRerankModel (interaction_rerank_model.py:96-109): only the input mapping + the reranker
+    const int Hc = c.ce_hidden, Ic = c.ce_intermediate;
+    req(m, "cross_encoder_input_mapping.weight", {Hc, D});
+    req(m, "cross_encoder_input_mapping.bias", {Hc});
+    if (c.model_kind == RR_MODEL_INTERACTION) {
+      const std::string p = "reranker.bert_model";
+      req(m, p + ".embeddings.position_embeddings.weight", {c.ce_max_pos, Hc});
+      req(m, p + ".embeddings.token_type_embeddings.weight", {c.type_vocab, Hc});
+      req(m, p + ".embeddings.LayerNorm.weight", {Hc});
+      req(m, p + ".embeddings.LayerNorm.bias", {Hc});
+      for (int i = 0; i < c.ce_layers; ++i) req_layer(m, p + ".encoder.layer." + std::to_string(i), Hc, Ic, false);
+    } else {   // MORES (mores_model.py:60-69)
+      for (int i = 0; i < c.ce_layers; ++i)
+        req_layer(m, "reranker.interaction_module." + std::to_string(i), Hc, Ic, true);
+    }
+    req(m, "reranker.classifier1.weight", {1, Hc});
+    req(m, "reranker.classifier1.bias", {1});
+    req(m, "reranker.classifier2.weight", {1, Hc});
+    req(m, "reranker.classifier2.bias", {1});
+    return;
+  }
   std::string p = "context_text_encoder.bert_model";
   req(m, p + ".embeddings.word_embeddings.weight", {c.vocab_size, H});
   req(m, p + ".embeddings.position_embeddings.weight", {c.max_pos, H});
@@ -439,6 +463,75 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   return RR_OK;
 }
 
+// CLS heads + (when this call covers every pair) the scoring head.  classifier1 -> "logits", classifier2 ->
+// "logits_secondary" (utils.py:105-108); for 2H_BCE the ranked logit is the second head (rerank_model.py:589-590).
+int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K, int pair_begin, bool full,
+              const float* labels, float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
+              int32_t* order_out) {
+  const rr_config& c = m->cfg;
+  const int Hc = c.ce_hidden, N = Bq * K;
+  float* out_a = logits_out + pair_begin;
+  float* out_b = logits2_out ? logits2_out + pair_begin : w.l2;
+  if (c.loss_kind == RR_LOSS_2H_BCE) {
+    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
+           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
+  } else {
+    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
+           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls1_w, m->cls1_b, m->cls2_w, m->cls2_b, out_a, out_b, st));
+  }
+  if (full && (loss_out || scores_out || order_out)) {
+    const int has_pw = !std::isnan(c.pos_weight);
+    RR_RUN(m, st, RR_K_HEAD, 0.0, 12.0 * N,
+           rr_launch_head(logits_out, c.loss_kind == RR_LOSS_2H_BCE ? logits2_out : nullptr, labels, Bq, K, c.loss_kind,
+                          has_pw ? c.pos_weight : 1.0f, has_pw, scores_out, order_out, loss_out, w.part_l, w.part_w, st));
+  }
+  return RR_OK;
+}
+
+// CrossEncoder over AttentionFusionBertModel (utils.py:85-108, attention_fusion.py:61-160): Linear(D -> Hc) ->
+// embeddings(inputs_embeds) -> Lc layers.  Input: w.li16 [n*T, D], w.ce_bias [n, T]; output: w.h32 [n*T, Hc].
+int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T) {
+  const rr_config& c = m->cfg;
+  const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate, RT = n * T;
+  RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
+         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
+  for (int l = 0; l < c.ce_layers; ++l)
+    RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w));
+  m->tap_ce = w.h32;
+  m->tap_ce_elems = (size_t)RT * Hc;
+  return RR_OK;
+}
+
+// Workspace of the interaction rerankers: n local pairs, Lq query tokens, Lc context tokens.
+size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, char* base, Work* w) {
+  Bump b(base);
+  const size_t T = (size_t)Lq + Lc, RT = (size_t)n * T, Hc = c.ce_hidden, Ic = c.ce_intermediate, D = c.li_dim;
+  w->h32 = b.take<float>(RT * Hc);
+  w->pre = b.take<float>(RT * Hc);
+  w->h16 = b.take<bf16_t>(RT * Hc);
+  w->qkv = b.take<bf16_t>(RT * 3 * Hc);
+  w->ctx = b.take<bf16_t>(RT * Hc);
+  w->mid = b.take<bf16_t>(RT * Ic);
+  w->li16 = b.take<bf16_t>(RT * D);
+  w->ce_bias = b.take<float>(RT);
+  w->text_bias = b.take<float>((size_t)n * Lq);   // MORES: query-side self-attention bias
+  w->li32 = b.take<float>((size_t)n * Lc);        // MORES: context-side cross-attention bias
+  w->l1 = b.take<float>(n);
+  w->l2 = b.take<float>(n);
+  w->part_l = b.take<float>(Bq);
+  w->part_w = b.take<float>(Bq);
+  if (c.model_kind == RR_MODEL_MORES) {
+    w->a32 = b.take<float>((size_t)n * Lq * Hc);
+    w->a16 = b.take<bf16_t>((size_t)n * Lq * Hc);
+    w->q_c = b.take<bf16_t>((size_t)n * Lq * Hc);
+    w->enc16 = b.take<bf16_t>((size_t)n * Lc * Hc);       // doc = Linear(context_late_interaction)
+    w->kv_c = b.take<bf16_t>((size_t)n * Lc * 2 * Hc);
+    w->t32 = b.take<float>((size_t)Bq * Lq * Hc);          // Linear(query_late_interaction), per query
+  }
+  return (b.off + 255) & ~(size_t)255;
+}
+
 }  // namespace
 
 extern "C" {
@@ -494,6 +587,7 @@ int rr_create(const rr_config* cfg, rr_handle* out) {
   }
   if (hipSetDevice(c.device) != hipSuccess) return RR_ERR_HIP;
   if (c.compute_dtype != 0 && c.compute_dtype != 1) return bad("compute_dtype must be 0 (bf16) or 1 (fp16)");
+  if (c.model_kind < 0 || c.model_kind > 2) return bad("model_kind must be 0 (full context), 1 (interaction) or 2 (MORES)");
   rr_model* m = new rr_model();
   m->cfg = c;
   m->dt = c.compute_dtype;
@@ -558,6 +652,31 @@ int rr_finalize_weights(rr_handle h) {
   rr_model* m = h;
   const rr_config& c = m->cfg;
   RR_HIP(m, hipSetDevice(c.device));
+  if (c.model_kind != RR_MODEL_FULL_CONTEXT) {
+    RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
+    RR_TRY(up_f32(m, HT(m, "cross_encoder_input_mapping.bias"), &m->b_cemap));
+    m->ce_layers.resize(c.ce_layers);
+    if (c.model_kind == RR_MODEL_INTERACTION) {
+      const std::string q = "reranker.bert_model";
+      RR_TRY(up_f32(m, HT(m, q + ".embeddings.position_embeddings.weight"), &m->ce_pos));
+      RR_TRY(up_f32(m, HT(m, q + ".embeddings.token_type_embeddings.weight"), &m->ce_type));
+      RR_TRY(up_f32(m, HT(m, q + ".embeddings.LayerNorm.weight"), &m->ce_emb_g));
+      RR_TRY(up_f32(m, HT(m, q + ".embeddings.LayerNorm.bias"), &m->ce_emb_b));
+      for (int i = 0; i < c.ce_layers; ++i)
+        RR_TRY(pack_layer(m, q + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i]));
+    } else {
+      for (int i = 0; i < c.ce_layers; ++i)
+        RR_TRY(pack_layer(m, "reranker.interaction_module." + std::to_string(i), c.ce_heads, c.ce_hidden, true,
+                          &m->ce_layers[i]));
+    }
+    RR_TRY(up_f32(m, HT(m, "reranker.classifier1.weight"), &m->cls1_w));
+    RR_TRY(up_f32(m, HT(m, "reranker.classifier1.bias"), &m->cls1_b));
+    RR_TRY(up_f32(m, HT(m, "reranker.classifier2.weight"), &m->cls2_w));
+    RR_TRY(up_f32(m, HT(m, "reranker.classifier2.bias"), &m->cls2_b));
+    m->host.clear();
+    m->finalized = true;
+    return RR_OK;
+  }
   std::string p = "context_text_encoder.bert_model";
   RR_TRY(up_f32(m, HT(m, p + ".embeddings.word_embeddings.weight"), &m->word));
   RR_TRY(up_f32(m, HT(m, p + ".embeddings.position_embeddings.weight"), &m->pos));
@@ -636,6 +755,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   if (!h) return RR_ERR_BAD_ARG;
   rr_model* m = h;
   const rr_config& c = m->cfg;
+  if (c.model_kind != RR_MODEL_FULL_CONTEXT) return fail(m, RR_ERR_BAD_ARG, "rr_forward on an interaction model; use rr_forward_interaction");
   if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_forward before rr_finalize_weights");
   if (!input_ids || !attention_mask || !logits_out) return fail(m, RR_ERR_BAD_ARG, "rr_forward: null input_ids/attention_mask/logits_out");
   if (Bq <= 0 || K <= 0 || S <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_forward: Bq=%d K=%d S=%d", Bq, K, S);
@@ -694,7 +814,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   // ---- 768 -> 128 projection (no bias), mask, L2 normalise -> li16[:, :S]
   RR_GEMM(m, st, w.h16, Hd, m->w_li, nullptr, nullptr, 0, w.li32, D, R, D, Hd, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * R * D + 8.0 * R,
-         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, st));
+         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, 1, st));
 
   if (vision) {
     const int np = c.n_patches, PL = c.prefix_len, Vh = c.vision_hidden, mid = D * PL / 2, outd = D * PL;
@@ -705,7 +825,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
     RR_GEMM(m, st, w.cls16, Vh, m->w_vp0, m->b_vp0, nullptr, 0, w.vp_mid16, mid, nq, mid, Vh, EPI_BIAS_TANH_BF16, 2.0);
     RR_GEMM(m, st, w.vp_mid16, mid, m->w_vp2, m->b_vp2, nullptr, 0, w.vp_out32, outd, nq, outd, mid, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * PL * D,
-           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, m->dt, st));
+           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, m->dt, 1, st));
     // mapping network: input linear + self-attention block depend on the image only => per query
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, m->dt, st));
     RR_GEMM(m, st, w.pat16, Vh, m->w_min, m->b_min, nullptr, 0, w.t32, Hd, nq * np, Hd, Vh, EPI_BIAS_F32, 4.0);
@@ -756,38 +876,112 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
     }
     RR_GEMM(m, st, w.m16, Hd, m->w_mout, m->b_mout, nullptr, 0, w.mo32, D, n * np, D, Hd, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * np * D,
-           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, m->dt, st));
+           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, m->dt, 1, st));
   }
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)RT * D;
 
-  // ---- cross encoder: Linear(D -> Hc) -> embeddings(inputs_embeds) -> Lc layers -> CLS -> heads
-  RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
-  RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
-         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
-  for (int l = 0; l < c.ce_layers; ++l)
-    RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w));
-  m->tap_ce = w.h32;
-  m->tap_ce_elems = (size_t)RT * Hc;
+  RR_TRY(run_cross_encoder(m, st, w, n, T));
+  return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+                   order_out);
+}
 
-  // classifier1 -> "logits", classifier2 -> "logits_secondary" (utils.py:105-108).  For 2H_BCE the ranked
-  // logit is the second head (rerank_model.py:589-590).
-  float* out_a = logits_out + pair_begin;
-  float* out_b = logits2_out ? logits2_out + pair_begin : w.l2;
-  if (c.loss_kind == RR_LOSS_2H_BCE) {
-    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
-           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
-  } else {
-    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
-           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls1_w, m->cls1_b, m->cls2_w, m->cls2_b, out_a, out_b, st));
+/* InteractionRerankModel.forward (interaction_rerank_model.py:110-166) from the retriever's late-interaction
+ * tensors.  NORMAL: cat(query, context) -> Linear -> CrossEncoder; MORES (mores_model.py:21-94): Lc layers of
+ * cross-attention(query -> doc) -> self-attention -> FFN over the query tokens. */
+int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                           const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
+                           int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                           float* scores_out, int32_t* order_out, void* hip_stream) {
+  if (!h) return RR_ERR_BAD_ARG;
+  rr_model* m = h;
+  const rr_config& c = m->cfg;
+  if (c.model_kind == RR_MODEL_FULL_CONTEXT) return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction on a full-context model");
+  if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction before rr_finalize_weights");
+  if (!query_li || !context_li || !query_mask || !context_mask || !logits_out)
+    return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction: null tensor");
+  if (Bq <= 0 || K <= 0 || Lq <= 0 || Lc <= 0) return fail(m, RR_ERR_BAD_SHAPE, "Bq=%d K=%d Lq=%d Lc=%d", Bq, K, Lq, Lc);
+  const int N = Bq * K, T = Lq + Lc;
+  if (pair_begin < 0 || pair_end > N || pair_begin >= pair_end)
+    return fail(m, RR_ERR_BAD_SHAPE, "pair slice [%d,%d) outside [0,%d)", pair_begin, pair_end, N);
+  if (c.model_kind == RR_MODEL_INTERACTION && T > c.ce_max_pos)
+    return fail(m, RR_ERR_BAD_SHAPE, "sequence %d exceeds cross_encoder_max_position_embeddings %d", T, c.ce_max_pos);
+  const bool full = pair_begin == 0 && pair_end == N;
+  if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && labels)
+    return fail(m, RR_ERR_BAD_ARG, "Labels should not be provided for negative sampling loss function");
+  if (!full && (loss_out || scores_out || order_out))
+    return fail(m, RR_ERR_BAD_ARG, "loss/scores/order need the full pair range; use rr_head after gathering logits");
+  if (c.loss_kind == RR_LOSS_2H_BCE && full && (loss_out || scores_out) && !logits2_out)
+    return fail(m, RR_ERR_BAD_ARG, "2H_BCE head needs logits2_out");
+  if (K > 4096 && (loss_out || scores_out || order_out)) return fail(m, RR_ERR_UNSUPPORTED, "K=%d > 4096", K);
+
+  hipStream_t st = (hipStream_t)hip_stream;
+  RR_HIP(m, hipSetDevice(c.device));
+  const int n = pair_end - pair_begin, q_lo = pair_begin / K, nq = (pair_end - 1) / K - q_lo + 1;
+  Work w{};
+  const size_t need = layout_interaction(c, n, Bq, Lq, Lc, nullptr, &w);
+  RR_TRY(ensure_ws(m, need, st));
+  layout_interaction(c, n, Bq, Lq, Lc, m->ws, &w);
+  m->last_stream = st;
+  const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate;
+  const float* cli = context_li + (size_t)pair_begin * Lc * D;
+  const float* cm = context_mask + (size_t)pair_begin * Lc;
+
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 8.0 * n * T,
+         rr_launch_interaction_bias(query_mask, cm, n, Lq, Lc, pair_begin, K, w.ce_bias, w.text_bias, w.li32, st));
+  // operands in 16 bits, query rows broadcast to the K pairs of the query (repeat_interleave, :128-129)
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * Lq * D,
+         rr_launch_li_normalize(query_li, nullptr, 0, n, Lq, D, T, 0, pair_begin, K, 0, w.li16, m->dt, 0, st));
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * Lc * D,
+         rr_launch_li_normalize(cli, nullptr, 0, n, Lc, D, T, Lq, 0, 1, 0, w.li16, m->dt, 0, st));
+  m->tap_li = w.li16;
+  m->tap_li_elems = (size_t)n * T * D;
+
+  if (c.model_kind == RR_MODEL_INTERACTION) {
+    RR_TRY(run_cross_encoder(m, st, w, n, T));
+    return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+                     order_out);
   }
-  if (full && (loss_out || scores_out || order_out)) {
-    const int has_pw = !std::isnan(c.pos_weight);
-    RR_RUN(m, st, RR_K_HEAD, 0.0, 12.0 * N,
-           rr_launch_head(logits_out, c.loss_kind == RR_LOSS_2H_BCE ? logits2_out : nullptr, labels, Bq, K, c.loss_kind,
-                          has_pw ? c.pos_weight : 1.0f, has_pw, scores_out, order_out, loss_out, w.part_l, w.part_w, st));
+
+  // ---- MORES: hidden = Linear(query) [n*Lq, Hc] (no embeddings, no LayerNorm), doc = Linear(context) [n*Lc, Hc]
+  // gather the two token groups out of the concatenated 16-bit buffer into contiguous GEMM operands
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * Lq * D, rr_launch_gather_rows(w.li16, w.a16, n, Lq, T, D * 2, 0, 1, 0, st));
+  RR_GEMM(m, st, w.a16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.h32, Hc, n * Lq, Hc, D, EPI_BIAS_F32, 4.0);
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * Lq * Hc, rr_launch_f32_to_bf16(w.h32, w.h16, (size_t)n * Lq * Hc, m->dt, st));
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * Lc * D,
+         rr_launch_gather_rows((const char*)w.li16 + (size_t)Lq * D * 2, w.ctx, n, Lc, T, D * 2, 0, 1, 0, st));
+  RR_GEMM(m, st, w.ctx, D, m->w_cemap, m->b_cemap, nullptr, 0, w.enc16, Hc, n * Lc, Hc, D, EPI_BIAS_BF16, 2.0);
+  (void)nq;
+  for (int l = 0; l < c.ce_layers; ++l) {
+    const LayerW& L = m->ce_layers[l];
+    const int rq = n * Lq;
+    // cross-attention first (MORES_BertLayer.forward, mores_model.py:31-41): queries from the query tokens, keys/values from doc
+    RR_GEMM(m, st, w.h16, Hc, L.wq_c, L.bq_c, nullptr, 0, w.q_c, Hc, rq, Hc, Hc, EPI_BIAS_BF16, 2.0);
+    RR_GEMM(m, st, w.enc16, Hc, L.wkv_c, L.bkv_c, nullptr, 0, w.kv_c, 2 * Hc, n * Lc, 2 * Hc, Hc, EPI_BIAS_BF16, 2.0);
+    RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)Lq * Lc * Hc, 2.0 * n * (2.0 * Lq + 2.0 * Lc) * Hc,
+           rr_launch_attention(w.q_c, Hc, 1, 0, w.kv_c, w.kv_c + Hc, 2 * Hc, w.li32, n, c.ce_heads, Lq, Lc, w.ctx, Hc,
+                               m->dt, st));
+    RR_GEMM(m, st, w.ctx, Hc, L.wo_c, L.bo_c, w.h32, Hc, w.pre, Hc, rq, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rq * Hc,
+           rr_launch_layernorm(w.pre, L.lncg, L.lncb, c.ln_eps, rq, Hc, w.a32, w.a16, m->dt, st));
+    // self-attention over the query tokens
+    RR_GEMM(m, st, w.a16, Hc, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hc, rq, 3 * Hc, Hc, EPI_BIAS_BF16, 2.0);
+    RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)Lq * Lq * Hc, 8.0 * rq * Hc,
+           rr_launch_attention(w.qkv, 3 * Hc, 1, 0, w.qkv + Hc, w.qkv + 2 * Hc, 3 * Hc, w.text_bias, n, c.ce_heads, Lq, Lq,
+                               w.ctx, Hc, m->dt, st));
+    RR_GEMM(m, st, w.ctx, Hc, L.wo, L.bo, w.a32, Hc, w.pre, Hc, rq, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rq * Hc,
+           rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, c.ln_eps, rq, Hc, w.a32, w.a16, m->dt, st));
+    // FFN
+    RR_GEMM(m, st, w.a16, Hc, L.w1, L.b1, nullptr, 0, w.mid, Ic, rq, Ic, Hc, EPI_BIAS_GELU_BF16, 2.0);
+    RR_GEMM(m, st, w.mid, Ic, L.w2, L.b2, w.a32, Hc, w.pre, Hc, rq, Hc, Ic, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rq * Hc,
+           rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, c.ln_eps, rq, Hc, w.h32, w.h16, m->dt, st));
   }
-  return RR_OK;
+  m->tap_ce = w.h32;
+  m->tap_ce_elems = (size_t)n * Lq * Hc;
+  return run_heads(m, st, w, n, Lq, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+                   order_out);
 }
 
 int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems) {

@@ -60,7 +60,8 @@ def make_arch(reranker_config=None, **overrides) -> dict:
              loss_fn=_get(reranker_config, "loss_fn", "BCE"),
              pos_weight=_get(reranker_config, "pos_weight", None),
              has_vision=1,
-             compute_dtype=_get(reranker_config, "compute_dtype", "bf16"))   # "bf16" | "fp16" MFMA operands
+             compute_dtype=_get(reranker_config, "compute_dtype", "bf16"),   # "bf16" | "fp16" MFMA operands
+             model_kind="full_context")
     a.update(_get(reranker_config, "arch", None) or {})
     a.update(overrides)
     return a
@@ -83,6 +84,23 @@ def weight_spec(a: dict) -> List[tuple]:
         return out
 
     s = []
+    kind = a.get("model_kind", "full_context")
+    if kind != "full_context":          # InteractionRerankModel: input mapping + reranker only
+        Hc, Ic = a["ce_hidden"], a["ce_intermediate"]
+        s += [("cross_encoder_input_mapping.weight", (Hc, D), "w"), ("cross_encoder_input_mapping.bias", (Hc,), "b")]
+        if kind == "interaction":
+            p = "reranker.bert_model"
+            s += [(f"{p}.embeddings.position_embeddings.weight", (a["ce_max_pos"], Hc), "e"),
+                  (f"{p}.embeddings.token_type_embeddings.weight", (a["type_vocab"], Hc), "e"),
+                  (f"{p}.embeddings.LayerNorm.weight", (Hc,), "g"), (f"{p}.embeddings.LayerNorm.bias", (Hc,), "b")]
+            for i in range(a["ce_layers"]):
+                s += layer(f"{p}.encoder.layer.{i}", Hc, Ic, False)
+        else:
+            for i in range(a["ce_layers"]):
+                s += layer(f"reranker.interaction_module.{i}", Hc, Ic, True)
+        s += [("reranker.classifier1.weight", (1, Hc), "w"), ("reranker.classifier1.bias", (1,), "b"),
+              ("reranker.classifier2.weight", (1, Hc), "w"), ("reranker.classifier2.bias", (1,), "b")]
+        return s
     p = "context_text_encoder.bert_model"
     s += [(f"{p}.embeddings.word_embeddings.weight", (a["vocab_size"], H), "e"),
           (f"{p}.embeddings.position_embeddings.weight", (a["max_pos"], H), "e"),
@@ -158,6 +176,10 @@ class RerankEngine:
         if cd not in L.COMPUTE_DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(L.COMPUTE_DTYPES)}, got {cd!r}")
         c.compute_dtype = L.COMPUTE_DTYPES[cd]
+        mk = arch.get("model_kind", "full_context")
+        if mk not in L.MODEL_KINDS:
+            raise ValueError(f"model_kind must be one of {sorted(L.MODEL_KINDS)}, got {mk!r}")
+        c.model_kind = L.MODEL_KINDS[mk]
         c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         L.check(self.lib.rr_create(C.byref(c), C.byref(h)), None, "rr_create")
@@ -245,6 +267,37 @@ class RerankEngine:
                                     L.ptr(image_cls), L.ptr(image_patches), Bq, K, S, L.ptr(labels), pb, pe,
                                     L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores), L.ptr(order),
                                     stream), self.h, "rr_forward")
+        return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
+
+    def forward_interaction(self, query_li: torch.Tensor, context_li: torch.Tensor, query_mask: torch.Tensor,
+                            context_mask: torch.Tensor, Bq: int, K: int, labels: Optional[torch.Tensor] = None,
+                            want_scores: bool = False, want_order: bool = False,
+                            pair_range: Optional[Sequence[int]] = None, want_loss: bool = True):
+        """Interaction rerankers: late-interaction tensors [Bq,Lq,D] / [N,Lc,D] and 0/1 masks [Bq,Lq] / [N,Lc]."""
+        dev = self.device
+        N = context_li.shape[0]
+        assert N == Bq * K and query_li.shape[0] == Bq, \
+            f"{tuple(query_li.shape)}, {tuple(context_li.shape)}, {K - 1}"        # interaction_rerank_model.py:123
+        Lq, Lc = query_li.shape[1], context_li.shape[1]
+        f32 = dict(device=dev, dtype=torch.float32)
+        query_li, context_li = query_li.to(**f32).contiguous(), context_li.to(**f32).contiguous()
+        query_mask = query_mask.reshape(Bq, Lq).to(**f32).contiguous()
+        context_mask = context_mask.reshape(N, Lc).to(**f32).contiguous()
+        if labels is not None:
+            assert labels.numel() == N
+            labels = labels.to(**f32).contiguous()
+        pb, pe = (0, N) if pair_range is None else (int(pair_range[0]), int(pair_range[1]))
+        full = pb == 0 and pe == N
+        logits = torch.empty(N, **f32)
+        logits2 = torch.empty(N, **f32)
+        loss = torch.empty((), **f32) if (full and want_loss) else None
+        scores = torch.empty(N, **f32) if (full and want_scores) else None
+        order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if (full and want_order) else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(self.lib.rr_forward_interaction(self.h, L.ptr(query_li), L.ptr(context_li), L.ptr(query_mask),
+                                                L.ptr(context_mask), Bq, K, Lq, Lc, L.ptr(labels), pb, pe,
+                                                L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
+                                                L.ptr(order), stream), self.h, "rr_forward_interaction")
         return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
 
     def head(self, logits: torch.Tensor, logits2: Optional[torch.Tensor], labels: Optional[torch.Tensor], Bq: int,
@@ -370,3 +423,45 @@ class FullContextRerankModel(torch.nn.Module):
         return self.forward_ids(enc["input_ids"].to(dev), enc["attention_mask"].to(dev),
                                 enc["token_type_ids"].to(dev), num_negative_examples, cls, patches,
                                 labels if labels else None)
+
+
+class InteractionRerankModel(torch.nn.Module):
+    """Drop-in for the reference's `InteractionRerankModel` (interaction_rerank_model.py:86-166), inference only:
+    `config.interaction_type` "MORES" selects the MORES stack (mores_model.py), anything else the CrossEncoder."""
+
+    def __init__(self, config, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None):
+        super().__init__()
+        self.config = config
+        kind = "mores" if _get(config, "interaction_type", "NORMAL") == "MORES" else "interaction"
+        arch = make_arch(config, model_kind=kind, has_vision=0)
+        self.engine = RerankEngine(arch, device)
+        if state_dict is not None:
+            self.engine.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict: bool = False, prefix: str = ""):  # type: ignore[override]
+        return self.engine.load_state_dict(state_dict, strict=strict, prefix=prefix)
+
+    def forward(self, query_late_interaction, context_late_interaction, num_negative_examples, query_mask,
+                context_mask, preflmr_scores=None, fusion_multiplier=1, labels=None, **kw) -> RerankOutput:
+        if preflmr_scores is not None:
+            raise NotImplementedError("Attention adj (preflmr_scores) is not implemented on this path")
+        K = num_negative_examples + 1
+        Bq = query_late_interaction.size(0)
+        N = context_late_interaction.size(0)
+        assert Bq * K == N, f"{query_late_interaction.shape}, {context_late_interaction.shape}, {num_negative_examples}"
+        arch = self.engine.arch
+        labels_t = None
+        if labels is not None:
+            assert isinstance(labels, list), "Labels must be a list"
+            if arch["loss_fn"] == "negative_sampling":
+                raise AssertionError("Labels should not be provided for negative sampling loss function")
+            labels_t = torch.tensor(labels, dtype=torch.float32, device=self.engine.device)
+        r = self.engine.forward_interaction(query_late_interaction, context_late_interaction, query_mask, context_mask,
+                                            Bq, K, labels_t, **kw)
+        logits = r["logits"]
+        logits = logits.view(Bq, K) if arch["loss_fn"] == "negative_sampling" else logits.view(N, 1)
+        out = RerankOutput(loss=r["loss"], logits=logits)
+        for k in ("scores", "order", "logits2"):
+            if r.get(k) is not None:
+                out[k] = r[k]
+        return out

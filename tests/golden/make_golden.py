@@ -111,6 +111,92 @@ class HFAssembly:
         return loss, logits, hs, Q
 
 
+class HFInteraction:
+    """Stock-HF restatement of InteractionRerankModel (interaction_rerank_model.py:96-166): NORMAL = BertModel on
+    inputs_embeds; MORES = HF BertLayer(is_decoder, add_cross_attention) sub-modules called in the order of
+    MORES_BertLayer.forward (mores_model.py:21-57): crossattention -> attention -> feed-forward."""
+
+    def __init__(self, cfg: O.OracleConfig, w, mores: bool):
+        from transformers.models.bert.modeling_bert import BertLayer
+        self.cfg, self.w, self.mores = cfg, w, mores
+        if mores:
+            c = hf_cfg(cfg.ce_hidden, cfg.ce_layers, cfg.ce_heads, cfg.ce_intermediate, cfg.ce_max_pos, cfg.vocab_size,
+                       cfg.ln_eps, is_decoder=True, add_cross_attention=True)
+            self.layers = []
+            for i in range(cfg.ce_layers):
+                L = BertLayer(c, layer_idx=i)
+                load_prefixed(L, w, f"reranker.interaction_module.{i}.")
+                self.layers.append(L)
+        else:
+            self.ce = BertModel(hf_cfg(cfg.ce_hidden, cfg.ce_layers, cfg.ce_heads, cfg.ce_intermediate, cfg.ce_max_pos,
+                                       cfg.vocab_size, cfg.ln_eps), add_pooling_layer=True)
+            load_prefixed(self.ce, w, "reranker.bert_model.")
+
+    def lin(self, x, name):
+        return torch.nn.functional.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"))
+
+    @torch.no_grad()
+    def forward(self, q, c, qm, cm, K, labels):
+        cfg = self.cfg
+        Bq = q.shape[0]
+        qq, qmm = q.repeat_interleave(K, 0), qm.repeat_interleave(K, 0)
+        if self.mores:
+            h = self.lin(qq, "cross_encoder_input_mapping")
+            doc = self.lin(c, "cross_encoder_input_mapping")
+            fmin = torch.finfo(torch.float32).min
+            qb = (1.0 - qmm)[:, None, None, :] * fmin
+            cb = (1.0 - cm)[:, None, None, :] * fmin
+            for L in self.layers:
+                a, _ = L.crossattention(h, None, doc, cb)
+                b, _ = L.attention(a, qb)
+                h = L.feed_forward_chunk(b)
+            cls = h[:, 0]
+        else:
+            x = self.lin(torch.cat((qq, c), 1), "cross_encoder_input_mapping")
+            cls = self.ce(inputs_embeds=x, attention_mask=torch.cat((qmm, cm), 1)).last_hidden_state[:, 0]
+        l1, l2 = self.lin(cls, "reranker.classifier1"), self.lin(cls, "reranker.classifier2")
+        logits, lab = O.prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)
+        loss = O.loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)
+        if cfg.loss_fn == "2H_BCE":
+            logits = logits[:, 1].unsqueeze(1)
+        return loss, logits
+
+
+INTERACTION_CASES = {
+    # name: (cfg kwargs, Bq, K, Lq, Lc, mores, loss)
+    "int_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
+                 2, 3, 9, 40, False, "BCE"),
+    "mores_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
+                   2, 3, 9, 40, True, "negative_sampling"),
+    "int_base": (dict(ce_layers=3), 1, 6, 113, 512, False, "BCE"),          # ModPreFLMR-BERT shape, K cut to 6
+    "mores_base": (dict(ce_layers=5), 1, 6, 113, 512, True, "BCE"),         # ModPreFLMR-IB shape
+}
+
+
+def run_interaction_case(name, outdir):
+    kw, Bq, K, Lq, Lc, mores, loss = INTERACTION_CASES[name]
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = loss
+    w = O.make_interaction_weights(cfg, mores, seed=0)
+    q, c, qm, cm = O.make_interaction_inputs(cfg, Bq, K, Lq, Lc)
+    labels = None
+    if loss != "negative_sampling":
+        rng = np.random.Generator(np.random.PCG64(5))
+        labels = [float(x) for x in (rng.random(Bq * K) < 0.3)]
+    loss_hf, logits_hf = HFInteraction(cfg, w, mores).forward(q, c, qm, cm, K, labels)
+    out = O.interaction_forward(cfg, w, q, c, qm, cm, K, labels, mores)
+    d_logit = (out.logits - logits_hf).abs().max().item()
+    d_loss = (out.loss - loss_hf).abs().item()
+    print(f"[{name}] oracle-vs-HF: logits {d_logit:.3e} loss {d_loss:.3e}")
+    order = [O.rank_descending_stable(r) for r in logits_hf.view(Bq, -1).tolist()]
+    np.savez_compressed(os.path.join(outdir, f"{name}.npz"), cfg_json=np.array(repr(kw)), Bq=Bq, K=K, Lq=Lq, Lc=Lc,
+                        mores=mores, loss_fn=np.array(loss), query_li=q.numpy(), context_li=c.numpy(),
+                        query_mask=qm.numpy(), context_mask=cm.numpy(),
+                        labels=np.array(labels if labels is not None else [], dtype=np.float32),
+                        logits=logits_hf.numpy(), loss=np.array(loss_hf.item(), dtype=np.float32),
+                        order=np.array(order, dtype=np.int32), oracle_vs_hf=np.array([d_logit, d_loss]))
+
+
 CASES = {
     # name: (cfg kwargs, Bq, K, S, vision, regime, loss)
     "tiny": (dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_pos=64,
@@ -171,8 +257,11 @@ def run_case(name, outdir):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default=",".join(CASES))
+    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES)))
     a = ap.parse_args()
     torch.set_num_threads(8)
     for nm in a.which.split(","):
-        run_case(nm, os.path.dirname(os.path.abspath(__file__)))
+        if nm in INTERACTION_CASES:
+            run_interaction_case(nm, os.path.dirname(os.path.abspath(__file__)))
+        else:
+            run_case(nm, os.path.dirname(os.path.abspath(__file__)))

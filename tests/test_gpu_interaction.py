@@ -1,0 +1,97 @@
+"""GPU parity of the Interaction rerankers (ModPreFLMR-BERT = CrossEncoder over cat(query, context) tokens;
+ModPreFLMR-IB = MORES) through rr_forward_interaction, against the stock-HF goldens and the same-rounding oracle."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, O, arch_from_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    cfg = O.OracleConfig(**ast.literal_eval(str(g["cfg_json"])))
+    cfg.loss_fn = str(g["loss_fn"])
+    g["cfg"], g["mores"] = cfg, bool(g["mores"])
+    for k in ("Bq", "K", "Lq", "Lc"):
+        g[k] = int(g[k])
+    g["labels_list"] = [float(x) for x in g["labels"]] if g["labels"].size else None
+    return g
+
+
+def _engine(g, compute_dtype="bf16"):
+    import rmr_amd
+    arch = arch_from_cfg(g["cfg"], False, compute_dtype)
+    arch["model_kind"] = "mores" if g["mores"] else "interaction"
+    eng = rmr_amd.RerankEngine(arch)
+    w = O.make_interaction_weights(g["cfg"], g["mores"], seed=0)
+    eng.load_state_dict(w)
+    return eng, w
+
+
+@pytest.mark.parametrize("name", ["int_tiny", "mores_tiny", "int_base", "mores_base"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_interaction_matches_golden_and_oracle(name, dtype):
+    g = _load(name)
+    cfg, Bq, K = g["cfg"], g["Bq"], g["K"]
+    eng, w = _engine(g, dtype)
+    q, c = torch.from_numpy(g["query_li"]), torch.from_numpy(g["context_li"])
+    qm, cm = torch.from_numpy(g["query_mask"]), torch.from_numpy(g["context_mask"])
+    lab = torch.tensor(g["labels_list"]).cuda() if g["labels_list"] is not None else None
+    r = eng.forward_interaction(q.cuda(), c.cuda(), qm.cuda(), cm.cuda(), Bq, K, lab, want_scores=True, want_order=True)
+    torch.cuda.synchronize()
+    logits = r["logits"].cpu()
+    gold = torch.from_numpy(g["logits"]).reshape(-1)
+    d32 = (logits - gold).abs().max().item()
+    with torch.no_grad(), O.device_rounding(torch.bfloat16 if dtype == "bf16" else torch.float16) as mm:
+        emu = O.interaction_forward(cfg, w, q, c, qm, cm, K, g["labels_list"], g["mores"], mm=mm)
+    demu = (logits - emu.logits.reshape(-1)).abs().max().item()
+    print(f"[{name}/{dtype}] |dlogit| vs fp32 golden {d32:.2e}, vs same-rounding oracle {demu:.2e}")
+    assert torch.isfinite(logits).all()
+    if dtype == "fp16":
+        assert d32 <= 1e-3 and demu <= 1e-3
+    else:
+        assert d32 <= 8e-3 and demu <= 4e-3
+    assert abs(r["loss"].item() - float(g["loss"])) < 1e-2
+    assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in logits.view(Bq, K).tolist()]
+
+
+def test_module_interface_and_errors():
+    import rmr_amd
+    g = _load("int_tiny")
+    cfg = g["cfg"]
+    w = O.make_interaction_weights(cfg, False, seed=0)
+    conf = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn="BCE", pos_weight=None, interaction_type="NORMAL", arch=arch_from_cfg(cfg, False))
+    m = rmr_amd.InteractionRerankModel(conf, state_dict=w)
+    q, c = torch.from_numpy(g["query_li"]).cuda(), torch.from_numpy(g["context_li"]).cuda()
+    qm, cm = torch.from_numpy(g["query_mask"]).int().cuda(), torch.from_numpy(g["context_mask"]).int().cuda()
+    out = m(query_late_interaction=q, context_late_interaction=c, num_negative_examples=g["K"] - 1, query_mask=qm,
+            context_mask=cm, labels=g["labels_list"])
+    assert out.logits.shape == (g["Bq"] * g["K"], 1) and out.loss.dim() == 0
+    assert abs(out.loss.item() - float(g["loss"])) < 1e-2
+    with pytest.raises(NotImplementedError):
+        m(q, c, g["K"] - 1, qm, cm, preflmr_scores=torch.zeros(1))
+    with pytest.raises(AssertionError):
+        m(q, c, g["K"], qm, cm)
+    with pytest.raises(ValueError):                       # full-context entry point on an interaction handle
+        m.engine.forward_ids(torch.ones(2, 8, dtype=torch.int64).cuda(), torch.ones(2, 8, dtype=torch.int64).cuda(),
+                             None, 1, 2)
+
+
+def test_interaction_pair_slices_compose():
+    g = _load("mores_tiny")
+    eng, w = _engine(g)
+    Bq, K = g["Bq"], g["K"]
+    N = Bq * K
+    args = [torch.from_numpy(g[k]).cuda() for k in ("query_li", "context_li", "query_mask", "context_mask")]
+    full = eng.forward_interaction(*args, Bq, K, None, want_order=True)
+    a = eng.forward_interaction(*args, Bq, K, None, pair_range=(0, 2), want_loss=False)["logits"][:2]
+    b = eng.forward_interaction(*args, Bq, K, None, pair_range=(2, N), want_loss=False)["logits"][2:]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([a, b]), full["logits"])

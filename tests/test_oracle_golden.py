@@ -98,3 +98,22 @@ def test_flops_per_pair_matches_survey():
     assert O.flops_per_pair(cfg, 512, False) / 1e9 == pytest.approx(104.9, abs=0.3)   # SURVEY §8d c3 text-only
     assert O.flops_per_pair(cfg, 128, False) / 1e9 == pytest.approx(24.3, abs=0.2)    # c1
     assert O.flops_per_pair(cfg, 512, True) / 1e9 == pytest.approx(107.3, abs=0.5)    # c3
+
+
+@pytest.mark.parametrize("name", ["int_tiny", "mores_tiny"])
+def test_interaction_oracle_matches_golden(name):
+    import ast, os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg_json"])))
+    cfg.loss_fn = str(z["loss_fn"])
+    mores, K = bool(z["mores"]), int(z["K"])
+    w = O.make_interaction_weights(cfg, mores, seed=0)
+    labels = [float(x) for x in z["labels"]] if z["labels"].size else None
+    with torch.no_grad():
+        out = O.interaction_forward(cfg, w, torch.from_numpy(z["query_li"]), torch.from_numpy(z["context_li"]),
+                                    torch.from_numpy(z["query_mask"]), torch.from_numpy(z["context_mask"]), K, labels,
+                                    mores)
+    np.testing.assert_allclose(out.logits.numpy(), z["logits"], atol=2e-5, rtol=0)
+    assert abs(out.loss.item() - float(z["loss"])) < 2e-5
+    assert z["oracle_vs_hf"][0] < 1e-5
