@@ -165,6 +165,18 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
                float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
                int32_t* order_out, void* hip_stream);
 
+/* rr_forward_joint: RerankModel.forward (the "softmax"/2-head variant, rerank_model.py:171-331) from the joint
+ * sequence the caller assembled as the reference does (:204-224): joint_ids = cat(query_ids repeated K times,
+ * context_ids[:, 2 : 2 - query_len]) [N,S], same for the mask.  Inside: token types 0, query_mask with instruction
+ * masking (id != 0 and (pos > first instruction_token_id position or pos < 2), :481-506; instruction_token_id < 0
+ * = plain id != 0), cross-encoder token order [query | image | context] (:257-274), and the reference's
+ * `loss_fn(logits, logits)` (:328: labels are ignored, the loss uses the logits as targets).  Image features are
+ * mandatory (NotImplementedError for text_only, :184-185); `preflmr_scores` attention fusion is not supported. */
+int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+                     const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len,
+                     int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out,
+                     float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream);
+
 /* rr_forward_interaction: the Interaction rerankers, fed by the frozen retriever's late-interaction outputs
  * (Reranker_base_executor.py:877-885 builds the call).  All pointers DEVICE float32:
  *   query_li [Bq, Lq, li_dim], context_li [N, Lc, li_dim], query_mask [Bq, Lq] and context_mask [N, Lc] (0/1).

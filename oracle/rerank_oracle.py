@@ -364,6 +364,71 @@ def full_context_forward(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Ten
     return OracleOutput(loss=loss, logits=logits, taps=taps or {})
 
 
+def instruction_query_mask(input_ids: Tensor, instruction_token_id: Optional[int]) -> Tensor:
+    """`RerankModel.query_mask` (rerank_model.py:481-506): id != 0 and (index > sep or index < 2), sep = first position
+    of the instruction token (argmax of an indicator; rows without it give 0, then clamped to 1)."""
+    if instruction_token_id is None:
+        return token_mask(input_ids)
+    sep = torch.argmax((input_ids == instruction_token_id).int(), dim=1)
+    sep = torch.clamp(sep, min=1)
+    idx = torch.arange(input_ids.shape[1])[None, :]
+    return ((input_ids != 0) & ((idx > sep[:, None]) | (idx < 2))).to(torch.float32)
+
+
+def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_ids: Tensor, query_attention_mask: Tensor,
+                         context_input_ids: Tensor, context_attention_mask: Tensor, K: int, image_cls: Tensor,
+                         image_patches: Tensor, instruction_token_id: Optional[int] = None, mm=None,
+                         want_taps: bool = False) -> OracleOutput:
+    """`RerankModel.forward` (rerank_model.py:171-331) without attention fusion (preflmr_scores=None)."""
+    Bq, ql = query_input_ids.shape
+    N = Bq * K
+    assert N == context_input_ids.shape[0]                                                  # :188
+    S = context_input_ids.shape[1]
+    assert S == cfg.max_pos                                                                 # :202
+    q_ids = query_input_ids.repeat_interleave(K, 0)
+    q_am = query_attention_mask.repeat_interleave(K, 0)
+    lt, rt = 2, 2 - ql                                                                      # :204-205
+    joint_ids = torch.cat([q_ids, context_input_ids[:, lt:rt]], 1)                          # :207-215
+    joint_am = torch.cat([q_am, context_attention_mask[:, lt:rt]], 1)
+    taps = {} if want_taps else None
+    img_c = image_cls.repeat_interleave(K, 0)
+    img_p = image_patches.repeat_interleave(K, 0)
+    # query(): same encoder stage, token types default to 0, mask = query_mask(..., mask_instructions)
+    hs = text_encoder(cfg, w, joint_ids, joint_am, None, mm, taps)
+    text = linear(hs, w, "context_text_encoder_linear", mm)
+    mask = instruction_query_mask(joint_ids, instruction_token_id)
+    text = text * mask[..., None]
+    x = linear(img_c, w, "context_vision_projection.model.0", mm)
+    x = linear(torch.tanh(x), w, "context_vision_projection.model.2", mm)
+    prefix = x.view(N, -1, cfg.li_dim)
+    t = linear(img_p, w, "transformer_mapping_input_linear", mm)
+    enc = hs[:, : cfg.cross_attn_len]
+    enc_mask = extended_mask(torch.ones(N, enc.shape[1]))
+    for i in range(cfg.map_layers):
+        t = bert_layer(t, w, f"transformer_mapping_network.layer.{i}", cfg.heads, cfg.ln_eps, None, enc_h=enc,
+                       enc_mask=enc_mask, mm=mm)
+    t = linear(t, w, "transformer_mapping_output_linear", mm)
+    Q = F.normalize(torch.cat([text, prefix, t], 1), p=2, dim=2)
+    xin = linear(Q, w, "cross_encoder_input_mapping", mm)                                   # :237-239
+    P = xin.shape[1] - S
+    m = torch.cat([mask, torch.ones(N, P)], 1)                                              # :245-254
+    xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)                            # :257-264
+    m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)                                     # :267-274
+    l1, l2 = cross_encoder(cfg, w, xin, m, None, mm, taps)                                  # :321-325
+    logits, _ = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, None)                 # :327
+    # :328 `loss = self.loss_fn(logits, logits)` — the labels are ignored, the logits are their own targets
+    if cfg.loss_fn == "BCE":
+        pw = torch.tensor([cfg.pos_weight]) if cfg.pos_weight is not None else None
+        loss = F.binary_cross_entropy_with_logits(logits, logits, pos_weight=pw)
+    elif cfg.loss_fn == "2H_BCE":
+        cw = torch.tensor([1.0, cfg.pos_weight]) if cfg.pos_weight is not None else None
+        loss = F.cross_entropy(logits, logits, weight=cw)
+        logits = logits[:, 1].unsqueeze(1)                                                  # :329-330
+    else:
+        raise NotImplementedError("RerankModel + negative_sampling is not exercised by any reference config")
+    return OracleOutput(loss=loss, logits=logits, taps=taps or {})
+
+
 def mores_layer(h: Tensor, doc: Tensor, w: Dict[str, Tensor], p: str, heads: int, eps: float, qry_mask: Tensor,
                 cross_mask: Tensor, mm=None) -> Tensor:
     """`MORES_BertLayer.forward` (mores_model.py:21-57): cross-attention(query -> doc) FIRST, then self-attention

@@ -6,7 +6,7 @@ Only what the hot path needs lives here: `csrc/` (HIP kernels + the C ABI of lib
 Importing the package does not need a GPU; constructing a model does (no CPU fallback exists).
 """
 from ._lib import EXPORTED, LIB_PATH  # noqa: F401
-from .model import (FullContextRerankModel, InteractionRerankModel, RerankEngine, RerankOutput, make_arch,  # noqa: F401
+from .model import (FullContextRerankModel, InteractionRerankModel, RerankModel, RerankEngine, RerankOutput, make_arch,  # noqa: F401
                     synthetic_state_dict, weight_spec)
 from .sharding import shard_range, ShardedReranker  # noqa: F401
 from .ranking import rank_descending_stable, recall_precision_at_k  # noqa: F401

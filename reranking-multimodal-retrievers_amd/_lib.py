@@ -58,6 +58,8 @@ _SIGS = {
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
     "rr_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                              _P, _P, _P, _P, _P, _P]),
+    "rr_forward_joint": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                   _P, _P, _P, _P, _P, _P]),
     "rr_forward_interaction": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                          _P, _P, _P, _P, _P, _P]),
     "rr_head": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -137,14 +137,16 @@ __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restri
                                                            int ids_stride, int n_pairs, int rows_per_batch, int D,
                                                            int T, int t_off, int pair_off, int bdiv,
                                                            int src_batch_off, bf16_t* __restrict__ dst, int dt,
-                                                           int normalize) {
+                                                           int normalize, const float* __restrict__ maskf, int split,
+                                                           int shift) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_pairs * rows_per_batch) return;
   const int p = r / rows_per_batch, j = r - p * rows_per_batch;
   const int sb = (p + pair_off) / bdiv - src_batch_off;
   const float* s = src + ((size_t)sb * rows_per_batch + j) * D;
-  const float m = ids ? (ids[(size_t)p * ids_stride + j] != 0 ? 1.0f : 0.0f) : 1.0f;
+  const float m = maskf ? maskf[(size_t)p * rows_per_batch + j]
+                        : (ids ? (ids[(size_t)p * ids_stride + j] != 0 ? 1.0f : 0.0f) : 1.0f);
   const int n4 = D >> 2;
   float4 v[MAX_V4];
   float q = 0.f;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(256) void li_normalize_kernel(const float* __restri
     }
   }
   const float nrm = normalize ? fmaxf(sqrtf(wave_sum(q)), 1e-12f) : 1.0f;   // 0: plain convert/concat
-  bf16_t* d = dst + ((size_t)p * T + t_off + j) * D;
+  const int tj = t_off + j + (j >= split ? shift : 0);    // RerankModel reorders [query | image | context] (:257-264)
+  bf16_t* d = dst + ((size_t)p * T + tj) * D;
 #pragma unroll
   for (int i = 0; i < MAX_V4; ++i) {
     const int c4 = lane + 64 * i;
@@ -180,6 +183,38 @@ __global__ void key_bias_kernel(const int64_t* __restrict__ ids, const int64_t* 
   } else {
     ce_bias[i] = 0.f;
   }
+}
+
+// ---- RerankModel (ids signature): query_mask with instruction masking (rerank_model.py:481-506) and the
+// [query | image | context] reorder of the cross-encoder mask (:267-274).  One wave per pair.
+//   valid(s) = id != 0 && (s > sep || s < 2), sep = first position of the instruction token (clamped to >= 1;
+//   instruction_token < 0 switches the rule off).
+__global__ __launch_bounds__(256) void joint_masks_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ am,
+                                                          int n, int S, int P, int q_len, long long instruction_token,
+                                                          float* __restrict__ text_bias, float* __restrict__ li_mask,
+                                                          float* __restrict__ ce_bias) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int64_t* row = ids + (size_t)p * S;
+  int sep = 0x7fffffff;
+  if (instruction_token >= 0) {
+    for (int s = lane; s < S; s += 64)
+      if (row[s] == instruction_token) { sep = s; break; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sep = min(sep, __shfl_xor(sep, o, 64));
+    if (sep == 0x7fffffff) sep = 0;      // torch.argmax of an all-zero row is 0 ...
+    if (sep < 1) sep = 1;                // ... and positions < 1 are set to 1 (:491-493)
+  }
+  const int T = S + P;
+  for (int s = lane; s < S; s += 64) {
+    const bool valid = row[s] != 0 && (instruction_token < 0 || s > sep || s < 2);
+    text_bias[(size_t)p * S + s] = am[(size_t)p * S + s] != 0 ? 0.f : -1e30f;
+    li_mask[(size_t)p * S + s] = valid ? 1.f : 0.f;
+    const int t = s < q_len ? s : s + P;
+    ce_bias[(size_t)p * T + t] = valid ? 0.f : -1e30f;
+  }
+  for (int j = lane; j < P; j += 64) ce_bias[(size_t)p * T + q_len + j] = 0.f;
 }
 
 // ---- interaction rerankers: key bias over the concatenated [query tokens | context tokens] sequence from the
@@ -277,11 +312,12 @@ hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* 
 
 hipError_t rr_launch_li_normalize(const float* src, const int64_t* ids, int ids_stride, int n_pairs,
                                   int rows_per_batch, int D, int T, int t_off, int pair_off, int bdiv,
-                                  int src_batch_off, bf16_t* dst, int dt, int normalize, hipStream_t st) {
+                                  int src_batch_off, bf16_t* dst, int dt, int normalize, const float* maskf, int split,
+                                  int shift, hipStream_t st) {
   if (n_pairs <= 0 || rows_per_batch <= 0 || (D & 3) || D > 64 * 4 * MAX_V4 || bdiv <= 0) return hipErrorInvalidValue;
   const int rows = n_pairs * rows_per_batch;
   hipLaunchKernelGGL(li_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, src, ids, ids_stride, n_pairs,
-                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst, dt, normalize);
+                     rows_per_batch, D, T, t_off, pair_off, bdiv, src_batch_off, dst, dt, normalize, maskf, split, shift);
   return hipGetLastError();
 }
 
@@ -290,6 +326,14 @@ hipError_t rr_launch_key_bias(const int64_t* ids, const int64_t* am, int n, int 
   const int total = n * T;
   hipLaunchKernelGGL(key_bias_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ids, am, n, S, T, text_bias,
                      ce_bias);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_joint_masks(const int64_t* ids, const int64_t* am, int n, int S, int P, int q_len,
+                                 long long instruction_token, float* text_bias, float* li_mask, float* ce_bias,
+                                 hipStream_t st) {
+  hipLaunchKernelGGL(joint_masks_kernel, dim3((n + 3) / 4), dim3(256), 0, st, ids, am, n, S, P, q_len,
+                     instruction_token, text_bias, li_mask, ce_bias);
   return hipGetLastError();
 }
 

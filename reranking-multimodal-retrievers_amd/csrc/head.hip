@@ -69,6 +69,16 @@ __global__ __launch_bounds__(256) void head_query_kernel(const float* __restrict
       wsum += w;
       if (scores) scores[(size_t)qi * K + i] = 1.f / (1.f + expf(a - b));
     }
+  } else if (loss_kind == 3) {   // RerankModel quirk: loss_fn(logits, logits) with 2 heads = CE with the logits
+    // themselves as class-probability targets (rerank_model.py:328): -sum_c w_c t_c log_softmax(x)_c, mean over N
+    for (int i = tid; i < K; i += blockDim.x) {
+      const float a = x1[i], b = x[i];
+      const float mx = fmaxf(a, b), lse = mx + logf(expf(a - mx) + expf(b - mx));
+      const float w1 = has_pw ? pos_weight : 1.f;
+      lsum += -(a * (a - lse) + w1 * b * (b - lse));
+      if (scores) scores[(size_t)qi * K + i] = 1.f / (1.f + expf(a - b));
+    }
+    wsum = (float)K;
   } else {                       // listwise: CE(target = candidate 0) over the K logits
     float mx = -INFINITY;
     for (int i = tid; i < K; i += blockDim.x) mx = fmaxf(mx, x[i]);
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(256) void head_query_kernel(const float* __restrict
   }
   if (part_loss) {
     const float L = block_sum(lsum, red);
-    const float Wt = loss_kind == 0 ? (float)K : block_sum(wsum, red);
+    const float Wt = (loss_kind == 0 || loss_kind == 3) ? (float)K : block_sum(wsum, red);
     if (tid == 0) { part_loss[qi] = L; part_w[qi] = Wt; }
   }
 
@@ -130,7 +140,7 @@ hipError_t rr_launch_head(const float* logits, const float* logits_first, const 
                           int loss_kind, float pos_weight, int has_pw, float* scores, int32_t* order, float* loss,
                           float* part_loss, float* part_w, hipStream_t st) {
   if (Bq <= 0 || K <= 0 || K > MAXK) return hipErrorInvalidValue;
-  if (loss_kind == 1 && !logits_first) return hipErrorInvalidValue;
+  if ((loss_kind == 1 || loss_kind == 3) && !logits_first) return hipErrorInvalidValue;
   hipLaunchKernelGGL(head_query_kernel, dim3(Bq), dim3(256), 0, st, logits, logits_first, labels, K, loss_kind,
                      pos_weight, has_pw, scores, order, loss ? part_loss : nullptr, part_w);
   if (loss) hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(64), 0, st, part_loss, part_w, Bq, loss);

@@ -21,7 +21,9 @@ hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, cons
 hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
                                  int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
-                                  int, int, hipStream_t);
+                                  int, int, const float*, int, int, hipStream_t);
+hipError_t rr_launch_joint_masks(const int64_t*, const int64_t*, int, int, int, int, long long, float*, float*, float*,
+                                 hipStream_t);
 hipError_t rr_launch_interaction_bias(const float*, const float*, int, int, int, int, int, float*, float*, float*,
                                       hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
@@ -365,7 +367,7 @@ struct Bump {
 };
 
 struct Work {
-  float *h32, *pre, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w;
+  float *h32, *pre, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask;
   bf16_t *h16, *qkv, *ctx, *mid, *li16;
   // vision
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
@@ -390,6 +392,7 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   w->li16 = b.take<bf16_t>(RT * c.li_dim);
   w->text_bias = b.take<float>(R);
   w->ce_bias = b.take<float>(RT);
+  w->li_mask = b.take<float>(R);
   w->l1 = b.take<float>(n);
   w->l2 = b.take<float>(n);
   w->part_l = b.take<float>(Bq);
@@ -467,7 +470,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
 // "logits_secondary" (utils.py:105-108); for 2H_BCE the ranked logit is the second head (rerank_model.py:589-590).
 int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K, int pair_begin, bool full,
               const float* labels, float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
-              int32_t* order_out) {
+              int32_t* order_out, bool logits_as_targets = false) {
   const rr_config& c = m->cfg;
   const int Hc = c.ce_hidden, N = Bq * K;
   float* out_a = logits_out + pair_begin;
@@ -482,7 +485,8 @@ int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K,
   if (full && (loss_out || scores_out || order_out)) {
     const int has_pw = !std::isnan(c.pos_weight);
     RR_RUN(m, st, RR_K_HEAD, 0.0, 12.0 * N,
-           rr_launch_head(logits_out, c.loss_kind == RR_LOSS_2H_BCE ? logits2_out : nullptr, labels, Bq, K, c.loss_kind,
+           rr_launch_head(logits_out, c.loss_kind == RR_LOSS_2H_BCE ? logits2_out : nullptr, labels, Bq, K,
+                          (logits_as_targets && c.loss_kind == RR_LOSS_2H_BCE) ? 3 : c.loss_kind,
                           has_pw ? c.pos_weight : 1.0f, has_pw, scores_out, order_out, loss_out, w.part_l, w.part_w, st));
   }
   return RR_OK;
@@ -748,10 +752,14 @@ int rr_head(rr_handle h, const float* logits, const float* logits2, const float*
   return RR_OK;
 }
 
-int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
-               const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels,
-               int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
-               float* scores_out, int32_t* order_out, void* hip_stream) {
+// joint != 0: RerankModel.forward semantics (rerank_model.py:171-331) on the pre-assembled joint sequence:
+// token types all 0, query_mask with instruction masking, cross-encoder order [query | image | context], and the
+// reference's `loss_fn(logits, logits)` quirk (:328).
+static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask,
+                        const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int Bq, int K,
+                        int S, const float* labels, int pair_begin, int pair_end, float* logits_out,
+                        float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream,
+                        int joint, int q_len, long long instruction_token) {
   if (!h) return RR_ERR_BAD_ARG;
   rr_model* m = h;
   const rr_config& c = m->cfg;
@@ -777,6 +785,12 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   if (c.loss_kind == RR_LOSS_2H_BCE && full && (loss_out || scores_out) && !logits2_out)
     return fail(m, RR_ERR_BAD_ARG, "2H_BCE head needs logits2_out");
   if (K > 4096 && (loss_out || scores_out || order_out)) return fail(m, RR_ERR_UNSUPPORTED, "K=%d > 4096", K);
+  if (joint) {
+    if (!vision) return fail(m, RR_ERR_UNSUPPORTED, "text_only is not implemented for this model");   // rerank_model.py:184-185
+    if (q_len <= 0 || q_len >= S) return fail(m, RR_ERR_BAD_SHAPE, "query length %d outside (0,%d)", q_len, S);
+    if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && loss_out)
+      return fail(m, RR_ERR_UNSUPPORTED, "RerankModel with negative_sampling loss is not covered (no reference config)");
+  }
 
   hipStream_t st = (hipStream_t)hip_stream;
   RR_HIP(m, hipSetDevice(c.device));
@@ -795,7 +809,14 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   const int64_t* tts = token_type_ids ? token_type_ids + (size_t)pair_begin * S : nullptr;
 
   // ---- masks -> additive key bias (text: tokenizer mask; cross encoder: id != 0, vision = 1)
-  RR_RUN(m, st, RR_K_EMBED, 0.0, 16.0 * R + 8.0 * RT, rr_launch_key_bias(ids, am, n, S, T, w.text_bias, w.ce_bias, st));
+  const int txt_split = joint ? q_len : (1 << 30), txt_shift = joint ? P : 0;   // [query | image | context] reorder
+  const int vis_off = joint ? q_len : S;                                           // where the image tokens go
+  if (joint) {
+    RR_RUN(m, st, RR_K_EMBED, 0.0, 24.0 * R + 4.0 * RT,
+           rr_launch_joint_masks(ids, am, n, S, P, q_len, instruction_token, w.text_bias, w.li_mask, w.ce_bias, st));
+  } else {
+    RR_RUN(m, st, RR_K_EMBED, 0.0, 16.0 * R + 8.0 * RT, rr_launch_key_bias(ids, am, n, S, T, w.text_bias, w.ce_bias, st));
+  }
   // ---- text encoder (FLMRTextModel = BertModel)
   RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * R * Hd,
          rr_launch_embed_ln(ids, tts, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps, R, S, Hd, c.vocab_size,
@@ -814,7 +835,8 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
   // ---- 768 -> 128 projection (no bias), mask, L2 normalise -> li16[:, :S]
   RR_GEMM(m, st, w.h16, Hd, m->w_li, nullptr, nullptr, 0, w.li32, D, R, D, Hd, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * R * D + 8.0 * R,
-         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, 1, st));
+         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, 1, joint ? w.li_mask : nullptr,
+                                txt_split, txt_shift, st));
 
   if (vision) {
     const int np = c.n_patches, PL = c.prefix_len, Vh = c.vision_hidden, mid = D * PL / 2, outd = D * PL;
@@ -825,7 +847,8 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
     RR_GEMM(m, st, w.cls16, Vh, m->w_vp0, m->b_vp0, nullptr, 0, w.vp_mid16, mid, nq, mid, Vh, EPI_BIAS_TANH_BF16, 2.0);
     RR_GEMM(m, st, w.vp_mid16, mid, m->w_vp2, m->b_vp2, nullptr, 0, w.vp_out32, outd, nq, outd, mid, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * PL * D,
-           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, S, pair_begin, K, q_lo, w.li16, m->dt, 1, st));
+           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, vis_off, pair_begin, K, q_lo, w.li16, m->dt, 1,
+                                  nullptr, 1 << 30, 0, st));
     // mapping network: input linear + self-attention block depend on the image only => per query
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, m->dt, st));
     RR_GEMM(m, st, w.pat16, Vh, m->w_min, m->b_min, nullptr, 0, w.t32, Hd, nq * np, Hd, Vh, EPI_BIAS_F32, 4.0);
@@ -876,14 +899,33 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
     }
     RR_GEMM(m, st, w.m16, Hd, m->w_mout, m->b_mout, nullptr, 0, w.mo32, D, n * np, D, Hd, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * np * D,
-           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, S + PL, 0, 1, 0, w.li16, m->dt, 1, st));
+           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, vis_off + PL, 0, 1, 0, w.li16, m->dt, 1, nullptr, 1 << 30,
+                                  0, st));
   }
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)RT * D;
 
   RR_TRY(run_cross_encoder(m, st, w, n, T));
-  return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
-                   order_out);
+  return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
+                   loss_out, scores_out, order_out, joint != 0);
+}
+
+int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+               const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels,
+               int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+               float* scores_out, int32_t* order_out, void* hip_stream) {
+  return forward_full(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, Bq, K, S, labels,
+                      pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, 0, 0,
+                      -1);
+}
+
+int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+                     const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len,
+                     int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out,
+                     float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return forward_full(h, joint_input_ids, joint_attention_mask, nullptr, image_cls, image_patches, Bq, K, S, nullptr,
+                      pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, 1,
+                      query_len, (long long)instruction_token_id);
 }
 
 /* InteractionRerankModel.forward (interaction_rerank_model.py:110-166) from the retriever's late-interaction
@@ -931,9 +973,9 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
          rr_launch_interaction_bias(query_mask, cm, n, Lq, Lc, pair_begin, K, w.ce_bias, w.text_bias, w.li32, st));
   // operands in 16 bits, query rows broadcast to the K pairs of the query (repeat_interleave, :128-129)
   RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * Lq * D,
-         rr_launch_li_normalize(query_li, nullptr, 0, n, Lq, D, T, 0, pair_begin, K, 0, w.li16, m->dt, 0, st));
+         rr_launch_li_normalize(query_li, nullptr, 0, n, Lq, D, T, 0, pair_begin, K, 0, w.li16, m->dt, 0, nullptr, 1 << 30, 0, st));
   RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * Lc * D,
-         rr_launch_li_normalize(cli, nullptr, 0, n, Lc, D, T, Lq, 0, 1, 0, w.li16, m->dt, 0, st));
+         rr_launch_li_normalize(cli, nullptr, 0, n, Lc, D, T, Lq, 0, 1, 0, w.li16, m->dt, 0, nullptr, 1 << 30, 0, st));
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)n * T * D;
 

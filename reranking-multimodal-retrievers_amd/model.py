@@ -269,6 +269,32 @@ class RerankEngine:
                                     stream), self.h, "rr_forward")
         return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
 
+    def forward_joint(self, joint_input_ids: torch.Tensor, joint_attention_mask: torch.Tensor, Bq: int, K: int,
+                      query_len: int, image_cls: torch.Tensor, image_patches: torch.Tensor,
+                      instruction_token_id: Optional[int] = None, want_scores: bool = False, want_order: bool = False,
+                      pair_range: Optional[Sequence[int]] = None, want_loss: bool = True):
+        """RerankModel.forward semantics on the assembled joint sequence (see rr_forward_joint)."""
+        dev = self.device
+        N, S = joint_input_ids.shape
+        assert N == Bq * K
+        f32 = dict(device=dev, dtype=torch.float32)
+        cls = patches = None
+        if image_cls is not None:
+            cls, patches = image_cls.to(**f32).contiguous(), image_patches.to(**f32).contiguous()
+        pb, pe = (0, N) if pair_range is None else (int(pair_range[0]), int(pair_range[1]))
+        full = pb == 0 and pe == N
+        logits, logits2 = torch.empty(N, **f32), torch.empty(N, **f32)
+        loss = torch.empty((), **f32) if (full and want_loss) else None
+        scores = torch.empty(N, **f32) if (full and want_scores) else None
+        order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if (full and want_order) else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(self.lib.rr_forward_joint(self.h, L.ptr(joint_input_ids.contiguous()),
+                                          L.ptr(joint_attention_mask.contiguous()), L.ptr(cls), L.ptr(patches), Bq, K, S,
+                                          int(query_len), -1 if instruction_token_id is None else int(instruction_token_id),
+                                          pb, pe, L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
+                                          L.ptr(order), stream), self.h, "rr_forward_joint")
+        return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
+
     def forward_interaction(self, query_li: torch.Tensor, context_li: torch.Tensor, query_mask: torch.Tensor,
                             context_mask: torch.Tensor, Bq: int, K: int, labels: Optional[torch.Tensor] = None,
                             want_scores: bool = False, want_order: bool = False,
@@ -461,6 +487,59 @@ class InteractionRerankModel(torch.nn.Module):
         logits = r["logits"]
         logits = logits.view(Bq, K) if arch["loss_fn"] == "negative_sampling" else logits.view(N, 1)
         out = RerankOutput(loss=r["loss"], logits=logits)
+        for k in ("scores", "order", "logits2"):
+            if r.get(k) is not None:
+                out[k] = r[k]
+        return out
+
+
+class RerankModel(torch.nn.Module):
+    """Drop-in for the reference's `RerankModel` (rerank_model.py:76-331; the "softmax"/2-head variant), inference
+    only.  Extra optional config keys: `arch`, `image_feature_fn` (pixel_values -> (cls, patches)),
+    `instruction_token_id` (id of `mask_instruction_token`, rerank_model.py:161-169; None = no instruction masking)."""
+
+    def __init__(self, config, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None):
+        super().__init__()
+        self.config = config
+        self.engine = RerankEngine(make_arch(config), device)
+        self.image_feature_fn = _get(config, "image_feature_fn", None)
+        self.instruction_token_id = _get(config, "instruction_token_id", None)
+        self.context_vision_encoder = _FrozenStub()
+        if state_dict is not None:
+            self.engine.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict: bool = False, prefix: str = ""):  # type: ignore[override]
+        return self.engine.load_state_dict(state_dict, strict=strict, prefix=prefix)
+
+    def forward(self, query_input_ids, query_attention_mask, query_pixel_values, context_input_ids,
+                context_attention_mask, num_negative_examples, preflmr_scores=None, fusion_multiplier=1, labels=None,
+                image_features=None, **kw) -> RerankOutput:
+        if query_pixel_values is None and image_features is None:
+            raise NotImplementedError("text_only is not implemented for this model")        # rerank_model.py:184-185
+        if preflmr_scores is not None:
+            raise NotImplementedError("preflmr_scores attention fusion is not implemented on this path")
+        K = num_negative_examples + 1
+        Bq = query_input_ids.size(0)
+        N = Bq * K
+        assert N == context_input_ids.size(0)                                               # :188
+        if labels:
+            assert len(labels) == N                                                         # :189-190
+        ql, S = query_input_ids.size(1), context_input_ids.size(1)
+        assert S == self.engine.arch["max_pos"]                                             # :202
+        dev = self.engine.device
+        # joint sequence exactly as :191-224 builds it (index plumbing on device tensors, no arithmetic)
+        q_ids = query_input_ids.to(dev).repeat_interleave(K, dim=0)
+        q_am = query_attention_mask.to(dev).repeat_interleave(K, dim=0)
+        joint_ids = torch.cat([q_ids, context_input_ids.to(dev)[:, 2:2 - ql]], dim=1).to(torch.int64).contiguous()
+        joint_am = torch.cat([q_am, context_attention_mask.to(dev)[:, 2:2 - ql]], dim=1).to(torch.int64).contiguous()
+        if image_features is not None:
+            cls, patches = image_features
+        else:
+            if self.image_feature_fn is None:
+                raise NotImplementedError("query_pixel_values given but config.image_feature_fn (CLIP ViT) is not set")
+            cls, patches = self.image_feature_fn(query_pixel_values)
+        r = self.engine.forward_joint(joint_ids, joint_am, Bq, K, ql, cls, patches, self.instruction_token_id, **kw)
+        out = RerankOutput(loss=r["loss"], logits=r["logits"].view(N, 1))
         for k in ("scores", "order", "logits2"):
             if r.get(k) is not None:
                 out[k] = r[k]

@@ -162,6 +162,58 @@ class HFInteraction:
         return loss, logits
 
 
+def run_rerankmodel_case(outdir, name="rm_tiny"):
+    """RerankModel.forward (ids signature) with instruction masking and the [query|image|context] reorder."""
+    kw = dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_pos=64, ce_hidden=128, ce_heads=2,
+              ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64, vision_hidden=128, prefix_len=4, n_patches=9,
+              cross_attn_len=32, pos_weight=2.0)
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = "2H_BCE"                      # the one reference config using RerankModel is the 2-head variant
+    Bq, K, S, ql, instr = 2, 3, 64, 8, 1999
+    w = O.make_weights(cfg, seed=0, vision=True)
+    rng = np.random.Generator(np.random.PCG64(7))
+    q_ids = torch.from_numpy(rng.integers(1000, 1990, size=(Bq, ql)))
+    q_ids[:, 0] = 101
+    q_ids[0, 5] = instr                          # query 0 has an instruction separator at position 5; query 1 has none
+    q_am = torch.ones(Bq, ql, dtype=torch.int64)
+    c_ids, c_am, _ = O.make_pair_batch(cfg, Bq, K, S, seed=3, regime="realistic")
+    img = O.make_image_feats(cfg, Bq)
+    hf = HFAssembly(cfg, w, True)
+    # HF restatement of the same graph
+    with torch.no_grad():
+        N = Bq * K
+        jq, jm = q_ids.repeat_interleave(K, 0), q_am.repeat_interleave(K, 0)
+        j_ids = torch.cat([jq, c_ids[:, 2:2 - ql]], 1)
+        j_am = torch.cat([jm, c_am[:, 2:2 - ql]], 1)
+        hs = hf.text(input_ids=j_ids, attention_mask=j_am).last_hidden_state
+        mask = O.instruction_query_mask(j_ids, instr)
+        text = hf.lin(hs, "context_text_encoder_linear") * mask.unsqueeze(2)
+        cc, pt = img[0].repeat_interleave(K, 0), img[1].repeat_interleave(K, 0)
+        x = hf.lin(torch.tanh(hf.lin(cc, "context_vision_projection.model.0")),
+                   "context_vision_projection.model.2").view(N, -1, cfg.li_dim)
+        t = hf.lin(pt, "transformer_mapping_input_linear")
+        enc = hs[:, : cfg.cross_attn_len]
+        t = hf.mapnet(t, encoder_hidden_states=enc, encoder_attention_mask=torch.zeros(N, 1, 1, enc.shape[1])).last_hidden_state
+        t = hf.lin(t, "transformer_mapping_output_linear")
+        Q = torch.nn.functional.normalize(torch.cat([text, x, t], 1), p=2, dim=2)
+        xin = hf.lin(Q, "cross_encoder_input_mapping")
+        m = torch.cat([mask, torch.ones(N, xin.shape[1] - S)], 1)
+        xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)
+        m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)
+        cls = hf.ce(inputs_embeds=xin, attention_mask=m).last_hidden_state[:, 0]
+        l12 = torch.cat((hf.lin(cls, "reranker.classifier1"), hf.lin(cls, "reranker.classifier2")), 1)
+        loss_hf = torch.nn.functional.cross_entropy(l12, l12, weight=torch.tensor([1.0, cfg.pos_weight]))
+        logits_hf = l12[:, 1:2]
+        out = O.rerank_model_forward(cfg, w, q_ids, q_am, c_ids, c_am, K, img[0], img[1], instr)
+    d_logit, d_loss = (out.logits - logits_hf).abs().max().item(), (out.loss - loss_hf).abs().item()
+    print(f"[{name}] oracle-vs-HF: logits {d_logit:.3e} loss {d_loss:.3e}")
+    np.savez_compressed(os.path.join(outdir, f"{name}.npz"), cfg_json=np.array(repr(kw)), Bq=Bq, K=K, S=S, ql=ql,
+                        instruction_token_id=instr, query_input_ids=q_ids.numpy(), query_attention_mask=q_am.numpy(),
+                        context_input_ids=c_ids.numpy(), context_attention_mask=c_am.numpy(),
+                        image_cls=img[0].numpy(), image_patches=img[1].numpy(), logits=logits_hf.numpy(),
+                        loss=np.array(loss_hf.item(), dtype=np.float32), oracle_vs_hf=np.array([d_logit, d_loss]))
+
+
 INTERACTION_CASES = {
     # name: (cfg kwargs, Bq, K, Lq, Lc, mores, loss)
     "int_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
@@ -257,11 +309,13 @@ def run_case(name, outdir):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES)))
+    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny"]))
     a = ap.parse_args()
     torch.set_num_threads(8)
     for nm in a.which.split(","):
-        if nm in INTERACTION_CASES:
+        if nm == "rm_tiny":
+            run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)))
+        elif nm in INTERACTION_CASES:
             run_interaction_case(nm, os.path.dirname(os.path.abspath(__file__)))
         else:
             run_case(nm, os.path.dirname(os.path.abspath(__file__)))

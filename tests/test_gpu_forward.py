@@ -200,3 +200,36 @@ def test_module_interface_returns_loss_and_logits():
     assert len(out.logits.squeeze().tolist()) == g["Bq"]                        # caller's .squeeze().tolist()
     assert abs(out.loss.detach().cpu().item() - float(g["loss"])) < 1e-2
     assert list(m.context_vision_encoder.named_parameters()) == []
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_rerank_model_ids_signature(dtype):
+    """RerankModel.forward (ids call signature): joint sequence, instruction masking, [query|image|context] reorder,
+    2-head logits and the reference's loss_fn(logits, logits) quirk — against the stock-HF golden."""
+    import ast, os
+    import numpy as np
+    import rmr_amd
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "rm_tiny.npz"), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg_json"])))
+    cfg.loss_fn = "2H_BCE"
+    w = O.make_weights(cfg, seed=0, vision=True)
+    conf = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn="2H_BCE", pos_weight=cfg.pos_weight, instruction_token_id=int(z["instruction_token_id"]),
+                arch=arch_from_cfg(cfg, True, dtype))
+    m = rmr_amd.RerankModel(conf, state_dict=w)
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    K = int(z["K"])
+    out = m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"),
+            K - 1, image_features=(t("image_cls"), t("image_patches")), want_order=True)
+    torch.cuda.synchronize()
+    d = (out.logits.cpu() - torch.from_numpy(z["logits"])).abs().max().item()
+    print(f"[rm_tiny/{dtype}] |dlogit| vs fp32 golden {d:.2e}, loss {out.loss.item():.6f} vs {float(z['loss']):.6f}")
+    assert d < (1e-3 if dtype == "fp16" else 2e-3)
+    assert abs(out.loss.item() - float(z["loss"])) < 2e-3
+    assert out.logits.shape == (int(z["Bq"]) * K, 1)
+    with pytest.raises(NotImplementedError):
+        m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"), K - 1)
+    with pytest.raises(NotImplementedError):
+        m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"), K - 1,
+          image_features=(t("image_cls"), t("image_patches")), preflmr_scores=torch.zeros(1))
