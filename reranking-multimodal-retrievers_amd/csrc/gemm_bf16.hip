@@ -46,6 +46,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_wave_b
       : "v"(gsrc), "s"(lds_dst_wave_base)
       : "memory");
 }
+// same, global address = 64-bit scalar base + 32-bit per-lane byte offset (keeps 1 VGPR per source instead of 2)
+__device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_dst_wave_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -57,6 +70,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -599,7 +613,303 @@ __global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ 
   stamp(stamps, 3);
 }
 
+// Variant H ("half-tile ring"): 256x256x64 K-tiles, 8 waves (wr = wave>>2, wc = wave&3).  The LDS ring holds
+// 8 half-tile slots of 16 KiB: {A rows 0-127, B rows 0-127, B rows 128-255, A rows 128-255} x 2 tile parities, and a
+// slot is refilled by LDS-DMA as soon as its fragments have been copied to registers, so ~5 half-tiles (80 KiB)
+// stay in flight instead of one drained 64-KiB tile (tools/dma_probe.hip: 66 vs 53 GB/s per CU).  Every K-tile
+// is 4 phases, one output quadrant (64x32 per wave, 16 MFMAs) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); the
+// fragments a phase needs are read from LDS during the PREVIOUS phase, behind that phase's MFMAs.
+//   phase p of tile t:  [ds_read fragments for the next phase] [DMA half-tile 4(t+2)+p] [16 MFMAs]
+//                       [s_waitcnt vmcnt(N): the half-tiles the NEXT phase reads have landed] [lgkmcnt(0)] [s_barrier]
+// RAW: every wave waits for its own DMA pieces before the barrier that precedes their first ds_read.
+// WAR: a slot read in phase p is refilled only after barrier(p).  N counts exactly the DMA instructions issued
+// after the needed half-tile (2 per half-tile per wave), so the wait is exact in the tail as well.
+template <int EPI, bool LDS_EPI, int DT>
+__global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ A, int lda,
+                                                     const bf16_t* __restrict__ W, int ldw,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ resid, int ldr,
+                                                     void* __restrict__ Cv, int ldc, int M, int N, int Kd,
+                                                     int tiles_n, int nwg, unsigned long long* stamps) {
+  stamp(stamps, 0);
+  constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- DMA sources: half-tile j in {0:A0, 1:B0, 2:B1, 3:A1}; this wave moves pieces 2*wave, 2*wave+1 (8 rows each).
+  // 32-bit byte offsets from the (scalar) A / W base: operands are < 4 GiB.
+  uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);          // row inside the half-tile
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    so_a0[i] = (uint32_t)(((size_t)min(m0 + r, M - 1) * lda + c * 8) * 2);
+    so_a1[i] = (uint32_t)(((size_t)min(m0 + 128 + r, M - 1) * lda + c * 8) * 2);
+    so_b0[i] = (uint32_t)(((size_t)min(n0 + r, N - 1) * ldw + c * 8) * 2);
+    so_b1[i] = (uint32_t)(((size_t)min(n0 + 128 + r, N - 1) * ldw + c * 8) * 2);
+  }
+  const uint32_t lds_base = lds_addr(lds);
+  const int nk = Kd / BK, H = 4 * nk;
+  // half-tile (t, J): slot = parity (t&1) * 4 + J; J is a compile-time constant at every call site
+#define RR_DMA(t_, J)                                                                                             \
+  {                                                                                                               \
+    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(A + (size_t)(t_) * BK) : (const void*)(W + (size_t)(t_) * BK); \
+    const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
+    glds16_so(sb_, so_[0], dst_);                                                                                 \
+    glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
+  }
+  // wait until half-tile h_need (and everything older) has landed; h_last = newest half-tile issued so far
+  auto wait_half = [&](int h_need, int h_last) {
+    if (h_need >= H) return;
+    const int after = h_last - h_need;                        // half-tiles issued after the needed one
+    if (after >= 5) wait_vmcnt<10>();
+    else if (after == 4) wait_vmcnt<8>();
+    else if (after == 3) wait_vmcnt<6>();
+    else if (after == 2) wait_vmcnt<4>();
+    else if (after == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+  };
+
+  // ---- fragment addresses inside a half-tile slot (swizzle term is the same for every 16-row block); the two
+  // 32-deep k-steps of a fragment differ by chunk ^ 4 = byte offset ^ 64
+  const int a_off = swz128(wr * 64 + (lane & 15), lane >> 4);
+  const int b_off = swz128(wc * 32 + (lane & 15), lane >> 4);
+  auto read_a = [&](const char* slot, int ks, bf16x8 (&f)[4]) {
+    const char* b = slot + (ks ? (a_off ^ 64) : a_off);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) f[mt] = *(const bf16x8*)(b + mt * 2048);
+  };
+  auto read_b = [&](const char* slot, int ks, bf16x8 (&f)[2]) {
+    const char* b = slot + (ks ? (b_off ^ 64) : b_off);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(b + nt * 2048);
+  };
+
+  f32x4 acc[4][2][4];   // [quadrant 2*hA+hB][nt][mt]; lane: m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Register fragments: A of the current row half (both k-steps), B0 (kept p0..p3) and B1 (p1..p2).  Fragments for a
+  // k-step are fetched one 8-MFMA block ahead of their use, so nothing is double-buffered: 64 fragment + 128
+  // accumulator registers.
+  bf16x8 AF0[4], AF1[4], B0K0[2], B0K1[2], B1K0[2], B1K1[2];
+
+#define RR_BLK(Q, AF, BF)                                                                          \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
+      acc[Q][nt][mt] = mfma16<DT>(BF[nt], AF[mt], acc[Q][nt][mt]);
+#define RR_SBAR() __builtin_amdgcn_sched_barrier(0)
+#define RR_PHASE_END(g_need, g_last)                     \
+  RR_SBAR();                                             \
+  wait_half(g_need, g_last);                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+  __builtin_amdgcn_s_barrier();                          \
+  RR_SBAR();
+
+  // ---- prologue: half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3}); first fragments of tile 0
+  RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
+  if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
+  const int g_pro = min(H - 1, 6);
+  wait_half(2, g_pro);                                      // A0(0), B0(0), B1(0) landed (my pieces)
+  __builtin_amdgcn_s_barrier();
+  stamp(stamps, 1);
+  read_a(lds + 0 * HALF, 0, AF0);
+  read_b(lds + 1 * HALF, 0, B0K0);
+
+  for (int t = 0; t < nk; ++t) {
+    const char* sl = lds + (t & 1) * 4 * HALF;               // this tile's slots: +0 A0, +1 B0, +2 B1, +3 A1
+    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;         // next tile's
+    // ---- p0: quadrant (A0, B0)
+    read_a(sl + 0 * HALF, 1, AF1);
+    read_b(sl + 1 * HALF, 1, B0K1);
+    RR_SBAR();
+    RR_BLK(0, AF0, B0K0)
+    RR_SBAR();
+    read_b(sl + 2 * HALF, 0, B1K0);
+    if (4 * (t + 1) + 3 < H) RR_DMA(t + 1, 3)                // refill: A1 of the next tile (its slot was freed in p2(t-1))
+    RR_SBAR();
+    RR_BLK(0, AF1, B0K1)
+    RR_PHASE_END(4 * t + 3, min(H - 1, 4 * (t + 1) + 3))    // A1(t) landed
+    // ---- p1: quadrant (A0, B1)
+    read_b(sl + 2 * HALF, 1, B1K1);
+    RR_SBAR();
+    RR_BLK(1, AF0, B1K0)
+    RR_SBAR();
+    read_a(sl + 3 * HALF, 0, AF0);
+    if (t + 2 < nk) RR_DMA(t + 2, 0)                         // slot A0 (free since barrier p0)
+    RR_SBAR();
+    RR_BLK(1, AF1, B1K1)
+    RR_PHASE_END(H, 0)                                       // p2 reads A1(t) only: already landed
+    // ---- p2: quadrant (A1, B1)
+    read_a(sl + 3 * HALF, 1, AF1);
+    RR_SBAR();
+    RR_BLK(3, AF0, B1K0)
+    RR_SBAR();
+    if (t + 2 < nk) RR_DMA(t + 2, 1)                         // slot B0 (free since barrier p0)
+    RR_SBAR();
+    RR_BLK(3, AF1, B1K1)
+    RR_PHASE_END(4 * (t + 1) + 1, min(H - 1, 4 * (t + 2) + 1))   // A0(t+1), B0(t+1) landed
+    // ---- p3: quadrant (A1, B0)
+    RR_BLK(2, AF0, B0K0)
+    RR_SBAR();
+    if (t + 1 < nk) {
+      read_a(sn + 0 * HALF, 0, AF0);
+      read_b(sn + 1 * HALF, 0, B0K0);
+    }
+    if (t + 2 < nk) RR_DMA(t + 2, 2)                         // slot B1 (free since barrier p1)
+    RR_SBAR();
+    RR_BLK(2, AF1, B0K1)
+    RR_PHASE_END(4 * (t + 1) + 2, min(H - 1, 4 * (t + 2) + 2))   // B1(t+1) landed
+  }
+#undef RR_DMA
+#undef RR_PHASE_END
+#undef RR_BLK
+#undef RR_SBAR
+  wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
+  stamp(stamps, 2);
+
+  // ---- epilogue (quadrant q = 2*hA + hB): rows hA*128 + wr*64 + mt*16 + (lane&15), cols hB*128 + wc*32 + nt*16 + (lane>>4)*4
+  constexpr bool F32_OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32);
+  if constexpr (LDS_EPI) {
+    constexpr int ES = F32_OUT ? 4 : 2;
+    constexpr int PITCH = BN * ES + 16;
+    constexpr int CPR = BN * ES / 16;
+    constexpr int NPASS = F32_OUT ? 2 : 1;                   // f32: one 128-row half (hA) per pass
+    constexpr int ROWS = F32_OUT ? 128 : 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hB = q & 1;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int gn = n0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+        const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
+                v3 = acc[q][nt][mt][3] + bv.w;
+          if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+          if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+          acc[q][nt][mt] = f32x4{v0, v1, v2, v3};
+        }
+      }
+    }
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int hA = q >> 1, hB = q & 1;
+        if (F32_OUT && hA != pass) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int cn = hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int r = (F32_OUT ? 0 : hA * 128) + wr * 64 + mt * 16 + (lane & 15);
+            char* dst = lds + r * PITCH + cn * ES;
+            if constexpr (F32_OUT) *(f32x4*)dst = acc[q][nt][mt];
+            else *(uint2*)dst = make_uint2(pack2<DT>(acc[q][nt][mt][0], acc[q][nt][mt][1]),
+                                           pack2<DT>(acc[q][nt][mt][2], acc[q][nt][mt][3]));
+          }
+        }
+      }
+      __syncthreads();
+      const int row_base = m0 + (F32_OUT ? pass * 128 : 0);
+#pragma unroll 4
+      for (int i = tid; i < ROWS * CPR; i += 512) {
+        const int r = i / CPR, c = i - r * CPR;
+        const int gm = row_base + r, gcol = n0 + c * (16 / ES);
+        if (gm < M && gcol < N) {
+          uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
+          if (EPI == EPI_BIAS_RESID_F32) {
+            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gcol);
+            float4 f = __builtin_bit_cast(float4, v);
+            f.x += rv.x; f.y += rv.y; f.z += rv.z; f.w += rv.w;
+            v = __builtin_bit_cast(uint4, f);
+          }
+          *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+        }
+      }
+      if (pass + 1 < NPASS) __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hA = q >> 1, hB = q & 1;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int gn = n0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+        if (gn >= N) continue;
+        const float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int gm = m0 + hA * 128 + wr * 64 + mt * 16 + (lane & 15);
+          if (gm >= M) continue;
+          float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
+                v3 = acc[q][nt][mt][3] + bv.w;
+          if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+          if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+          if (EPI == EPI_BIAS_RESID_F32) {
+            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
+            v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
+          }
+          if (F32_OUT) *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
+          else *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2<DT>(v0, v1), pack2<DT>(v2, v3));
+        }
+      }
+    }
+  }
+  stamp(stamps, 3);
+}
+
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
+
+template <bool LDS_EPI, int DT>
+hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+  if (LDS_EPI && (N & 7)) return hipErrorInvalidValue;
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
+  constexpr int ring = 8 * 128 * 128, stage_f32 = 128 * (256 * 4 + 16), stage_b16 = 256 * (256 * 2 + 16);
+  constexpr int so = LDS_EPI ? (stage_f32 > stage_b16 ? stage_f32 : stage_b16) : 0;
+  constexpr int lds_bytes = ring > so ? ring : so;
+  dim3 grid(nwg), block(512);
+  unsigned long long* stamps = g_stamps;
+#define RR_GEMM_CASE(E)                                                                                       \
+  case E: {                                                                                                   \
+    auto kern = gemm_kernel_h<E, LDS_EPI, DT>;                                                                \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      if (e != hipSuccess) return e;                                                                          \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
+                       tiles_n, nwg, stamps);                                                                 \
+    break;                                                                                                    \
+  }
+  switch (epilogue) {
+    RR_GEMM_CASE(EPI_BIAS_BF16)
+    RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
+    RR_GEMM_CASE(EPI_BIAS_F32)
+    RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
+    RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    default: return hipErrorInvalidValue;
+  }
+#undef RR_GEMM_CASE
+  return hipGetLastError();
+}
+
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 
 template <int STAGES>
@@ -680,7 +990,7 @@ int g_variant = -1;   // tuning override: RR_GEMM_VARIANT=0..3 (unset: shape heu
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 10) return -1;
+  if (v < -1 || v > 12) return -1;
   g_variant = v;
   return 0;
 }
@@ -710,17 +1020,18 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   }
   int v = g_variant;
   if (v < 0) {
-    // big problems: 256x256 tiles (1 workgroup/CU, 8 waves); small ones: 128x128 so the grid still fills 256 CUs.
-    // Epilogue: LDS-staged coalesced stores, except GELU whose ~18k cycles of VALU work per tile hide best behind
-    // the direct form's store issue (measured, tools/bench_gemm.py --stamps).
+    // big problems: 256x256 tiles, half-tile LDS ring (variant H) with the LDS-staged coalesced epilogue; small ones:
+    // 128x128 so the grid still fills 256 CUs (measured with tools/bench_gemm.py --stamps, profiles/).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    v = tiles256 >= 512 ? ((epilogue == EPI_BIAS_GELU_BF16 || (N & 7)) ? 2 : 10) : 0;
+    v = tiles256 >= 512 ? ((N & 7) ? 11 : 12) : 0;
   }
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
       case 2: return launch_cfg<256, 256, 2, 4, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
       case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
       default: return hipErrorInvalidValue;
     }
   }
@@ -737,6 +1048,8 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     case 7: RR_CFG(256, 128, 4, 2, 3, true);
     case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
     case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+    case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+    case 12: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
     case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
     default: return hipErrorInvalidValue;
   }
