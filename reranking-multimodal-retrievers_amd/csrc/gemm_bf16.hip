@@ -826,19 +826,34 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
       }
       __syncthreads();
       const int row_base = m0 + (F32_OUT ? pass * 128 : 0);
-#pragma unroll 4
-      for (int i = tid; i < ROWS * CPR; i += 512) {
-        const int r = i / CPR, c = i - r * CPR;
-        const int gm = row_base + r, gcol = n0 + c * (16 / ES);
-        if (gm < M && gcol < N) {
-          uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
-          if (EPI == EPI_BIAS_RESID_F32) {
-            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gcol);
-            float4 f = __builtin_bit_cast(float4, v);
-            f.x += rv.x; f.y += rv.y; f.z += rv.z; f.w += rv.w;
-            v = __builtin_bit_cast(uint4, f);
+      // stream the staged rows out, UNR 16-byte chunks per thread in flight at a time: the residual loads of a whole
+      // batch are issued before the first add/store so that ~64-128 KiB per CU are outstanding (the 4-deep form ran
+      // at ~8 B/clk/CU, below the ~12 B/clk/CU a pure streaming kernel reaches)
+      constexpr int UNR = 8;
+      for (int i0 = tid; i0 < ROWS * CPR; i0 += 512 * UNR) {
+        float4 rv[UNR];
+        if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * 512, r = i / CPR, c = i - r * CPR;
+            const int gm = row_base + r, gcol = n0 + c * (16 / ES);
+            rv[u] = (i < ROWS * CPR && gm < M && gcol < N) ? *(const float4*)(resid + (size_t)gm * ldr + gcol)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
           }
-          *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int i = i0 + u * 512, r = i / CPR, c = i - r * CPR;
+          const int gm = row_base + r, gcol = n0 + c * (16 / ES);
+          if (i < ROWS * CPR && gm < M && gcol < N) {
+            uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
+            if (EPI == EPI_BIAS_RESID_F32) {
+              float4 f = __builtin_bit_cast(float4, v);
+              f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
+              v = __builtin_bit_cast(uint4, f);
+            }
+            *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+          }
         }
       }
       if (pass + 1 < NPASS) __syncthreads();
