@@ -73,6 +73,7 @@ _SIGS = {
                                        C.c_int, _P, C.c_int, _P]),
     "rr_set_gemm_variant": (C.c_int, [C.c_int]),
     "rr_set_op_dtype": (C.c_int, [C.c_int]),
+    "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rr_set_gemm_stamps": (C.c_int, [_P]),
     "rr_set_gemm_stagger": (C.c_int, [C.c_int]),
     "rr_op_layernorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P]),

@@ -53,7 +53,8 @@ __device__ __forceinline__ void ln_store(const float4 (&v)[MAX_V4], RowStats st,
 // ---- LayerNorm over fp32 rows -> fp32 (residual stream) + bf16 (next GEMM operand)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int rows,
-                                                        int cols, float* __restrict__ o32, bf16_t* __restrict__ o16, int dt) {
+                                                        int cols, float* __restrict__ o32, bf16_t* __restrict__ o16, int dt,
+                                                        float2* __restrict__ stats_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < MAX_V4; ++i) v[i] = (lane + 64 * i < n4) ? xr[lane + 64 * i] : make_float4(0, 0, 0, 0);
   const RowStats st = row_stats(v, n4, lane, cols, eps);
+  if (stats_out && lane == 0) stats_out[row] = make_float2(st.mean, st.rstd);   // for the GEMM epilogue's ln_apply
   ln_store(v, st, gamma, beta, n4, lane, o32 ? o32 + (size_t)row * cols : nullptr,
            o16 ? o16 + (size_t)row * cols : nullptr, dt);
 }
@@ -288,7 +290,17 @@ hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* 
                                float* out_f32, bf16_t* out_bf16, int dt, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
-                     out_f32, out_bf16, dt);
+                     out_f32, out_bf16, dt, (float2*)nullptr);
+  return hipGetLastError();
+}
+
+// LayerNorm that also leaves (mean, rstd) per row; out_f32 may be null (the fp32 stream is then recomputed where it
+// is consumed, gemm_bf16.hip:ln_apply).
+hipError_t rr_launch_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                                     float* out_f32, bf16_t* out_bf16, float* stats_out, int dt, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4 || !stats_out) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
+                     out_f32, out_bf16, dt, (float2*)stats_out);
   return hipGetLastError();
 }
 

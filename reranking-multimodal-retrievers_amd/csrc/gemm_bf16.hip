@@ -102,6 +102,22 @@ __device__ __forceinline__ float fast_erf(float x) {
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+// Residual taken from a not-yet-normalised row: r = LayerNorm(x) recomputed on the fly from the row statistics the
+// LN kernel left behind ((x - mean) * rstd * gamma + beta, the very expression of elementwise.hip:ln_store).  This
+// lets the LN kernel skip writing the fp32 normalised stream (10 -> 6 bytes per element).
+struct LnResid {
+  const float2* stats;   // [rows] (mean, rstd) or nullptr = `resid` already holds the residual values
+  const float* gamma;
+  const float* beta;
+};
+__device__ __forceinline__ float4 ln_apply(float4 x, const LnResid& ln, int gm, int gn) {
+  if (!ln.stats) return x;
+  const float2 st = ln.stats[gm];
+  const float4 g = *(const float4*)(ln.gamma + gn), b = *(const float4*)(ln.beta + gn);
+  return make_float4((x.x - st.x) * st.y * g.x + b.x, (x.y - st.x) * st.y * g.y + b.y,
+                     (x.z - st.x) * st.y * g.z + b.z, (x.w - st.x) * st.y * g.w + b.w);
+}
+
 // ---- diagnostic cycle stamps (tools/bench_gemm.py --stamps): block entry / first tile ready / main loop done /
 // epilogue done, written by lane 0 of wave 0 into a buffer no kernel reads.  nullptr in every product launch.
 // De-synchronise the CUs: all workgroups of the first dispatch wave would otherwise reach their store epilogue at
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
                                                              const float* __restrict__ resid, int ldr,
                                                              void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                              int tiles_n, int nwg, unsigned long long* stamps,
-                                                             int stagger_unit) {
+                                                             int stagger_unit, LnResid ln) {
   if (stagger_unit > 0) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int NW = WM * WN;
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
                                                              const float* __restrict__ resid, int ldr,
                                                              void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                              int tiles_n, int nwg, unsigned long long* stamps,
-                                                             int stagger_unit) {
+                                                             int stagger_unit, LnResid ln) {
   if (stagger_unit > 0) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int NW = WM * WN;
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
         if (gm < M && gcol < N) {
           uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
           if (EPI == EPI_BIAS_RESID_F32) {
-            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gcol);
+            const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gcol), ln, gm, gcol);
             float4 f = __builtin_bit_cast(float4, v);
             f.x += rv.x; f.y += rv.y; f.z += rv.z; f.w += rv.w;
             v = __builtin_bit_cast(uint4, f);
@@ -463,7 +479,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
       if (EPI == EPI_BIAS_RESID_F32) {
-        const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
+        const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
         v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
       }
       if (F32_OUT) {
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ 
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ resid, int ldr,
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                     int tiles_n, int nwg, unsigned long long* stamps) {
+                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln) {
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, BKG = 32, WN = 4;
   constexpr int TM = 128, TN = 64, MT = 8, NT = 4;
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ 
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
       if (EPI == EPI_BIAS_RESID_F32) {
-        const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
+        const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
         v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
       }
       if (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32) {
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ resid, int ldr,
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                     int tiles_n, int nwg, unsigned long long* stamps) {
+                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln) {
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -830,6 +846,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
       // batch are issued before the first add/store so that ~64-128 KiB per CU are outstanding (the 4-deep form ran
       // at ~8 B/clk/CU, below the ~12 B/clk/CU a pure streaming kernel reaches)
       constexpr int UNR = 8;
+      // 512 threads cover 512/CPR whole rows per step, so a thread keeps ONE column chunk for the whole pass (its
+      // gamma/beta are loaded once) and a wave keeps one row per step (its LayerNorm statistics are a scalar load).
+      static_assert(512 % CPR == 0, "a wave must not straddle rows");
+      const int my_col = n0 + (tid % CPR) * (16 / ES);
+      float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == EPI_BIAS_RESID_F32 && ln.stats && my_col < N) {
+        lg = *(const float4*)(ln.gamma + my_col);
+        lb = *(const float4*)(ln.beta + my_col);
+      }
       for (int i0 = tid; i0 < ROWS * CPR; i0 += 512 * UNR) {
         float4 rv[UNR];
         if (EPI == EPI_BIAS_RESID_F32) {
@@ -837,8 +862,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           for (int u = 0; u < UNR; ++u) {
             const int i = i0 + u * 512, r = i / CPR, c = i - r * CPR;
             const int gm = row_base + r, gcol = n0 + c * (16 / ES);
-            rv[u] = (i < ROWS * CPR && gm < M && gcol < N) ? *(const float4*)(resid + (size_t)gm * ldr + gcol)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = i < ROWS * CPR && gm < M && gcol < N;
+            float4 x = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ln.stats) {
+              const int gm_s = __builtin_amdgcn_readfirstlane(min(gm, M - 1));     // wave-uniform row
+              const float2 st2 = ln.stats[gm_s];
+              x = make_float4((x.x - st2.x) * st2.y * lg.x + lb.x, (x.y - st2.x) * st2.y * lg.y + lb.y,
+                              (x.z - st2.x) * st2.y * lg.z + lb.z, (x.w - st2.x) * st2.y * lg.w + lb.w);
+            }
+            rv[u] = x;
           }
         }
 #pragma unroll
@@ -876,7 +908,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
           if (EPI == EPI_BIAS_RESID_F32) {
-            const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
+            const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
             v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
           }
           if (F32_OUT) *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
@@ -892,7 +924,7 @@ unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps
 
 template <bool LDS_EPI, int DT>
 hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
-                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   if (LDS_EPI && (N & 7)) return hipErrorInvalidValue;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
   constexpr int ring = 8 * 128 * 128, stage_f32 = 128 * (256 * 4 + 16), stage_b16 = 256 * (256 * 2 + 16);
@@ -910,7 +942,7 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
       attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps);                                                                 \
+                       tiles_n, nwg, stamps, ln);                                                             \
     break;                                                                                                    \
   }
   switch (epilogue) {
@@ -929,7 +961,7 @@ int g_stagger = 0;                        // start-skew unit in s_sleep(127) ste
 
 template <int STAGES>
 hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
-                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   if (Kd % 32 != 0) return hipErrorInvalidValue;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
   constexpr int lds_bytes = STAGES * 512 * 32 * 2;
@@ -945,7 +977,7 @@ hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
       attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps);                                                                 \
+                       tiles_n, nwg, stamps, ln);                                                             \
     break;                                                                                                    \
   }
   switch (epilogue) {
@@ -963,7 +995,7 @@ hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool LDS_EPI = false, int DT = 0>
 hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
-                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st) {
+                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
   constexpr int ring_bytes = STAGES * (BM + BN) * BK * 2;
   // staging image: f32 -> one row group (BM/WM rows x (4 BN + 16) B); bf16 -> the whole tile (BM x (2 BN + 16) B)
@@ -984,7 +1016,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
       attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, (BM == 256 && BN == 256 && nwg > 512) ? g_stagger : 0);         \
+                       tiles_n, nwg, stamps, (BM == 256 && BN == 256 && nwg > 512) ? g_stagger : 0, ln);     \
     break;                                                                                                    \
   }
   switch (epilogue) {
@@ -1020,10 +1052,24 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
   return 0;
 }
 
+hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
+                             const float* resid, int ldr, const float* ln_stats, const float* ln_gamma,
+                             const float* ln_beta, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
+                             hipStream_t st);
+
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
                           int epilogue, int dt, hipStream_t st) {
+  return rr_launch_gemm_ln(A, lda, W, ldw, bias, resid, ldr, nullptr, nullptr, nullptr, C, ldc, M, N, Kd, epilogue, dt, st);
+}
+
+hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
+                             const float* resid, int ldr, const float* ln_stats, const float* ln_gamma,
+                             const float* ln_beta, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
+                             hipStream_t st) {
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
+  if (ln_stats && (epilogue != EPI_BIAS_RESID_F32 || !ln_gamma || !ln_beta)) return hipErrorInvalidValue;
+  const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta};
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
   if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;
@@ -1042,16 +1088,16 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   }
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
-      case 0: return launch_cfg<128, 128, 2, 2, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-      case 2: return launch_cfg<256, 256, 2, 4, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-      case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-      case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-      case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+      case 0: return launch_cfg<128, 128, 2, 2, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 2: return launch_cfg<256, 256, 2, 4, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       default: return hipErrorInvalidValue;
     }
   }
 #define RR_CFG(BM_, BN_, WM_, WN_, ST_, P_) \
-  return launch_cfg<BM_, BN_, WM_, WN_, ST_, P_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st)
+  return launch_cfg<BM_, BN_, WM_, WN_, ST_, P_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln)
   switch (v) {
     case 0: RR_CFG(128, 128, 2, 2, 2, false);
     case 1: RR_CFG(128, 128, 2, 2, 4, false);
@@ -1061,11 +1107,11 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     case 5: RR_CFG(128, 128, 2, 2, 3, true);
     case 6: RR_CFG(256, 256, 2, 4, 2, true);
     case 7: RR_CFG(256, 128, 4, 2, 3, true);
-    case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-    case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-    case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-    case 12: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
-    case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st);
+    case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 12: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     default: return hipErrorInvalidValue;
   }
 #undef RR_CFG

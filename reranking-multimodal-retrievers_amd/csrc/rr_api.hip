@@ -26,6 +26,10 @@ hipError_t rr_launch_joint_masks(const int64_t*, const int64_t*, int, int, int, 
                                  hipStream_t);
 hipError_t rr_launch_interaction_bias(const float*, const float*, int, int, int, int, int, float*, float*, float*,
                                       hipStream_t);
+hipError_t rr_launch_layernorm_stats(const float*, const float*, const float*, float, int, int, float*, bf16_t*, float*,
+                                     int, hipStream_t);
+hipError_t rr_launch_gemm_ln(const bf16_t*, int, const bf16_t*, int, const float*, const float*, int, const float*,
+                             const float*, const float*, void*, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -367,7 +371,7 @@ struct Bump {
 };
 
 struct Work {
-  float *h32, *pre, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask;
+  float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask;
   bf16_t *h16, *qkv, *ctx, *mid, *li16;
   // vision
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
@@ -384,6 +388,9 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   const size_t Hm = imax(c.hidden, c.ce_hidden), Im = imax(c.intermediate, c.ce_intermediate);
   w->h32 = b.take<float>(Rm * Hm);
   w->pre = b.take<float>(Rm * Hm);
+  w->pre2 = b.take<float>(Rm * Hm);
+  w->stats_a = b.take<float>(Rm * 2);
+  w->stats_b = b.take<float>(Rm * 2);
   w->h16 = b.take<bf16_t>(Rm * Hm);
   w->qkv = b.take<bf16_t>(Rm * 3 * Hm);
   w->ctx = b.take<bf16_t>(Rm * Hm);
@@ -448,21 +455,53 @@ double gemm_bytes(double M, double N, double K, double out_elt) { return 2.0 * (
   RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, outb) + (((const void*)(resid) != nullptr) ? 4.0 * (M) * (N) : 0.0), \
          rr_launch_gemm(A, lda, W, K, bias, resid, ldr, C, ldc, M, N, K, epi, m->dt, st))
 
-// One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
+int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
+
+// Where a layer's residual comes from: either materialised fp32 rows (after an embedding LayerNorm), or the previous
+// LayerNorm's INPUT plus its row statistics and affine (the fp32 normalised stream is never written in between).
+struct ResidSrc {
+  const float* x;
+  const float* stats;   // nullptr = x holds the residual itself
+  const float* g;
+  const float* b;
+};
+
+#define RR_GEMM_LN(m, st, A, lda, W, bias, rs, C, ldc, M, N, K, outb)                                            \
+  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, outb) + 4.0 * (M) * (N),                     \
+         rr_launch_gemm_ln(A, lda, W, K, bias, (rs).x, N, (rs).stats, (rs).g, (rs).b, C, ldc, M, N, K,           \
+                           EPI_BIAS_RESID_F32, m->dt, st))
+
+// One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).  In: w.h16 (bf16 LayerNorm output of the
+// previous block) and `rs`; out: w.h16, `rs` updated to this layer's LN2 (and w.h32 when `want_h32`).
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
-              const float* key_bias, Work& w) {
+              const float* key_bias, Work& w, ResidSrc& rs, bool want_h32) {
   const int rows = batch * Tseq;
   RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
          rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
                              Tseq, w.ctx, Hd, m->dt, st));
-  RR_GEMM(m, st, w.ctx, Hd, L.wo, L.bo, w.h32, Hd, w.pre, Hd, rows, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
-  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
-         rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
+  if (!g_ln_lite) {   // reference dataflow for A/B runs: every LayerNorm writes the fp32 stream, residuals read it back
+    RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
+           rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
+    RR_GEMM(m, st, w.h16, Hd, L.w1, L.b1, nullptr, 0, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
+    const ResidSrc r0{w.h32, nullptr, nullptr, nullptr};
+    RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r0, w.pre, Hd, rows, Hd, I, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
+           rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
+    rs = r0;
+    return RR_OK;
+  }
+  RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
+  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 6.0 * rows * Hd,
+         rr_launch_layernorm_stats(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, nullptr, w.h16, w.stats_a, m->dt, st));
   RR_GEMM(m, st, w.h16, Hd, L.w1, L.b1, nullptr, 0, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
-  RR_GEMM(m, st, w.mid, I, L.w2, L.b2, w.h32, Hd, w.pre, Hd, rows, Hd, I, EPI_BIAS_RESID_F32, 4.0);
-  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
-         rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
+  const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
+  RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
+  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_h32 ? 10.0 : 6.0) * rows * Hd,
+         rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_h32 ? w.h32 : nullptr, w.h16, w.stats_b,
+                                   m->dt, st));
+  rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
   return RR_OK;
 }
 
@@ -500,8 +539,12 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T) {
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
          rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
-  for (int l = 0; l < c.ce_layers; ++l)
-    RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w));
+  {
+    ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
+    for (int l = 0; l < c.ce_layers; ++l)
+      RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs,
+                       l == c.ce_layers - 1));              // the CLS heads read the fp32 rows of the last layer
+  }
   m->tap_ce = w.h32;
   m->tap_ce_elems = (size_t)RT * Hc;
   return RR_OK;
@@ -513,6 +556,9 @@ size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, cha
   const size_t T = (size_t)Lq + Lc, RT = (size_t)n * T, Hc = c.ce_hidden, Ic = c.ce_intermediate, D = c.li_dim;
   w->h32 = b.take<float>(RT * Hc);
   w->pre = b.take<float>(RT * Hc);
+  w->pre2 = b.take<float>(RT * Hc);
+  w->stats_a = b.take<float>(RT * 2);
+  w->stats_b = b.take<float>(RT * 2);
   w->h16 = b.take<bf16_t>(RT * Hc);
   w->qkv = b.take<bf16_t>(RT * 3 * Hc);
   w->ctx = b.take<bf16_t>(RT * Hc);
@@ -821,8 +867,12 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * R * Hd,
          rr_launch_embed_ln(ids, tts, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps, R, S, Hd, c.vocab_size,
                             c.type_vocab, w.h32, w.h16, m->dt, st));
-  for (int l = 0; l < c.layers; ++l)
-    RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w));
+  {
+    ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
+    for (int l = 0; l < c.layers; ++l)
+      RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs,
+                       m->debug && l == c.layers - 1));
+  }
   if (m->debug) {
     const size_t el = (size_t)R * Hd;
     if (m->tap_text_elems < el) {
@@ -1081,6 +1131,12 @@ int rr_get_profile(rr_handle h, rr_profile* out, int reset) {
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------
+int rr_set_tuning(const char* key, int value) {
+  if (!key) return RR_ERR_BAD_ARG;
+  if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
+  return RR_ERR_BAD_ARG;
+}
+
 static int g_op_dt = 0;   // operand dtype used by the stand-alone rr_op_* entry points (rr_set_op_dtype)
 int rr_set_op_dtype(int dt) {
   if (dt != 0 && dt != 1) return RR_ERR_BAD_ARG;
