@@ -58,6 +58,27 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // 256-byte bank row => conflict-free.
 __device__ __forceinline__ int swz128(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
+// LDS-DMA of 64 x 16 B: LDS destination = wave-uniform byte address (M0) + lane*16, per-lane global source.
+// Issued from inline asm on purpose: hipcc's waitcnt pass treats the builtin form like a FLAT access and
+// then degrades every later `s_waitcnt lgkmcnt(N)` in the loop to lgkmcnt(0), which serialises the
+// ds_read -> MFMA software pipeline.  The DMA is counted by hand (wait_vmcnt below); no compiler-visible
+// VMEM load lives inside the main loop (cdna_hip_programming.md §5.7 item 1).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_wave_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_wave_base)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
