@@ -233,3 +233,43 @@ def test_rerank_model_ids_signature(dtype):
     with pytest.raises(NotImplementedError):
         m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"), K - 1,
           image_features=(t("image_cls"), t("image_patches")), preflmr_scores=torch.zeros(1))
+
+
+def test_batched_rerank_loop_on_device_orders():
+    """§8f-1: several queries per forward, device-side rank, reference-schema records, Recall@K — end to end on the GPU
+    against the same loop driven by the CPU oracle."""
+    import rmr_amd
+    g = load_golden("tiny")
+    cfg = g["cfg"]
+    cfg.loss_fn = "negative_sampling"
+    w = O.make_weights(cfg, 0, False)
+    eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, False, "fp16"))
+    eng.load_state_dict(w)
+    nq, K, S = 5, 6, g["S"]
+    ids, am, tt = O.make_pair_batch(cfg, nq, K, S, seed=77)
+    queries = [{"question_id": q, "retrieved_docs": [{"passage_id": f"d{q}_{k}", "content": ""} for k in range(K)],
+                "pos_item_ids": [f"d{q}_{(2 * q + 1) % K}"], "rows": slice(q * K, (q + 1) * K)} for q in range(nq)]
+
+    def fwd_gpu(batch):
+        rows = torch.cat([torch.arange(q["rows"].start, q["rows"].stop) for q in batch])
+        r = eng.forward_ids(ids[rows].cuda(), am[rows].cuda(), tt[rows].cuda(), len(batch), K, want_order=True)
+        return {"logits": r["logits"].view(len(batch), K).cpu(), "order": r["order"].cpu(), "loss": r["loss"].item()}
+
+    def fwd_oracle(batch):
+        rows = torch.cat([torch.arange(q["rows"].start, q["rows"].stop) for q in batch])
+        with torch.no_grad():
+            o = O.full_context_forward(cfg, w, ids[rows], am[rows], tt[rows], len(batch), K)
+        lg = o.logits.view(len(batch), K)
+        return {"logits": lg, "order": [O.rank_descending_stable(x) for x in lg.tolist()], "loss": o.loss.item()}
+
+    a = rmr_amd.rerank_dataset(queries, fwd_gpu, batch_queries=2, Ks=[1, 3, 6], docs_to_rerank=6)
+    b = rmr_amd.rerank_dataset(queries, fwd_oracle, batch_queries=2, Ks=[1, 3, 6], docs_to_rerank=6)
+    for ra, rb in zip(a["output"], b["output"]):
+        sa = [p["score"] for p in ra["top_ranking_passages"]]
+        sb = [p["score"] for p in rb["top_ranking_passages"]]
+        assert max(abs(x - y) for x, y in zip(sorted(sa), sorted(sb))) < 1e-3
+        gaps = [sb[i] - sb[i + 1] for i in range(K - 1)]
+        if min(gaps) > 2e-3:      # unambiguous oracle ranking -> identical ranking on the device
+            assert [p["passage_id"] for p in ra["top_ranking_passages"]] == [p["passage_id"] for p in rb["top_ranking_passages"]]
+    assert a["metrics"]["pos_item_ids_recall_at_6"] == 1.0 == b["metrics"]["pos_item_ids_recall_at_6"]
+    assert a["metrics"]["pos_item_ids_raw_recall_at_1"] == b["metrics"]["pos_item_ids_raw_recall_at_1"]
