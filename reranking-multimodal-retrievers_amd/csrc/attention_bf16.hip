@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         s1[4 * g + 0] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
       }
     }
+    // 32-way max; this file is built with -fno-honor-nans -mno-amdgpu-ieee (build.py) so that fmaxf lowers to bare
+    // v_max3_f32 — in IEEE mode hipcc canonicalises every MFMA output first (+32 VALU per tile).  No NaN can occur:
+    // inputs are finite and the only non-finite values are the -inf biases of out-of-range keys.
     mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
@@ -166,9 +169,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c));
       }
     }
-    float ps = 0.f;
+    // row sum over this lane's 32 probabilities, written as a tree so the adds pair up (v_pk_add_f32)
+    typedef __attribute__((ext_vector_type(2))) float f32x2v;
+    f32x2v acc2 = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ps += s0[r] + s1[r];
+    for (int r = 0; r < 16; r += 2) {
+      acc2 += f32x2v{s0[r], s0[r + 1]};
+      acc2 += f32x2v{s1[r], s1[r + 1]};
+    }
+    const float ps = acc2[0] + acc2[1];
     l_run = l_run * alpha + ps;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
