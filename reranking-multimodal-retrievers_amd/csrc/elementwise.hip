@@ -219,6 +219,52 @@ __global__ __launch_bounds__(256) void joint_masks_kernel(const int64_t* __restr
   for (int j = lane; j < P; j += 64) ce_bias[(size_t)p * T + q_len + j] = 0.f;
 }
 
+// ---- CLIP ViT front end (modeling_clip CLIPVisionEmbeddings as called through modeling_flmr.py:1701-1757):
+// im2col for the stride = kernel patch convolution: row (b, patch), column (c, ky, kx) — the order of the conv weight
+// [hidden, 3, ps, ps] flattened — zero-padded to Kp columns, written in the MFMA operand type.
+__global__ void vit_im2col_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int IS, int ps, int Kp,
+                                  int dt) {
+  const int g = IS / ps, np = g * g, Kd = 3 * ps * ps;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * np * Kp) return;
+  const int col = (int)(i % Kp);
+  const size_t rp = i / Kp;
+  const int p = (int)(rp % np), b = (int)(rp / np);
+  float v = 0.f;
+  if (col < Kd) {
+    const int c = col / (ps * ps), r = col - c * ps * ps, ky = r / ps, kx = r - ky * ps;
+    const int y = (p / g) * ps + ky, x = (p % g) * ps + kx;
+    v = px[(((size_t)b * 3 + c) * IS + y) * IS + x];
+  }
+  out[i] = (bf16_t)(pack2rt(v, 0.f, dt) & 0xffff);
+}
+
+// [class_embedding ; patch embeddings] + position_embedding -> pre_layrnorm -> fp32 residual stream (row = b*(np+1)+t)
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restrict__ patches, const float* __restrict__ cls_emb,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int rows, int T,
+                                                           int cols, float* __restrict__ o32) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2, b = row / T, t = row - b * T;
+  const float4* src = t == 0 ? (const float4*)cls_emb : (const float4*)(patches + ((size_t)b * (T - 1) + (t - 1)) * cols);
+  const float4* pr = (const float4*)(pos + (size_t)t * cols);
+  float4 v[MAX_V4];
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float4 a = src[c4], c = pr[c4];
+      v[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    } else {
+      v[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  const RowStats st = row_stats(v, n4, lane, cols, eps);
+  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, nullptr, 0);
+}
+
 // ---- interaction rerankers: key bias over the concatenated [query tokens | context tokens] sequence from the
 // retriever's 0/1 masks (interaction_rerank_model.py:153); also the two separate biases MORES needs.
 __global__ void interaction_bias_kernel(const float* __restrict__ qmask, const float* __restrict__ cmask, int n, int Lq,
@@ -338,6 +384,20 @@ hipError_t rr_launch_key_bias(const int64_t* ids, const int64_t* am, int n, int 
   const int total = n * T;
   hipLaunchKernelGGL(key_bias_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ids, am, n, S, T, text_bias,
                      ce_bias);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_vit_im2col(const float* px, bf16_t* out, int B, int IS, int ps, int Kp, int dt, hipStream_t st) {
+  const size_t total = (size_t)B * (IS / ps) * (IS / ps) * Kp;
+  hipLaunchKernelGGL(vit_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, px, out, B, IS, ps, Kp, dt);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_vit_embed_ln(const float* patches, const float* cls_emb, const float* pos, const float* gamma,
+                                  const float* beta, float eps, int rows, int T, int cols, float* o32, hipStream_t st) {
+  if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vit_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, patches, cls_emb, pos, gamma, beta, eps,
+                     rows, T, cols, o32);
   return hipGetLastError();
 }
 

@@ -80,6 +80,8 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 // tanh(x) = 1 - 2/(exp(2x)+1) on the fast exp/rcp units (abs err ~1e-7; saturates correctly at +-inf)
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+// CLIP's quick_gelu: x * sigmoid(1.702 x)
+__device__ __forceinline__ float qgelu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 // Residual taken from a not-yet-normalised row: r = LayerNorm(x) recomputed on the fly from the row statistics the
@@ -267,6 +269,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
               v2 = acc[nt][mt][4 * g + 2] + bv.z, v3 = acc[nt][mt][4 * g + 3] + bv.w;
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
         if (EPI == EPI_BIAS_RESID_F32) {
           const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
           v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -406,6 +410,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
               v3 = acc[nt][mt][3] + bv.w;
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
         if constexpr (F32_OUT) acc[nt][mt] = f32x4{v0, v1, v2, v3};
         else pk[nt][mt] = make_uint2(pack2<DT>(v0, v1), pack2<DT>(v2, v3));
       }
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
             v3 = acc[nt][mt][3] + bv.w;
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
       if (EPI == EPI_BIAS_RESID_F32) {
         const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
         v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -595,6 +602,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ 
             v3 = acc[nt][mt][3] + bv.w;
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
       if (EPI == EPI_BIAS_RESID_F32) {
         const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
         v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -626,7 +634,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ resid, int ldr,
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln) {
+                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
+                                                     int stagger_unit) {
+  if (stagger_unit > 0) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -798,6 +808,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
                 v3 = acc[q][nt][mt][3] + bv.w;
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+          if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
           acc[q][nt][mt] = f32x4{v0, v1, v2, v3};
         }
       }
@@ -887,6 +900,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
                 v3 = acc[q][nt][mt][3] + bv.w;
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+          if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
           if (EPI == EPI_BIAS_RESID_F32) {
             const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
             v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -901,6 +917,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 }
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
+
+int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 
 template <bool LDS_EPI, int DT>
 hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
@@ -922,7 +940,7 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
       attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln);                                                             \
+                       tiles_n, nwg, stamps, ln, nwg > 512 ? g_stagger : 0);                                                             \
     break;                                                                                                    \
   }
   switch (epilogue) {
@@ -931,13 +949,13 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
     RR_GEMM_CASE(EPI_BIAS_F32)
     RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
     RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
     default: return hipErrorInvalidValue;
   }
 #undef RR_GEMM_CASE
   return hipGetLastError();
 }
 
-int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 
 template <int STAGES>
 hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
@@ -966,6 +984,7 @@ hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
     RR_GEMM_CASE(EPI_BIAS_F32)
     RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
     RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
     default: return hipErrorInvalidValue;
   }
 #undef RR_GEMM_CASE
@@ -1005,6 +1024,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
     RR_GEMM_CASE(EPI_BIAS_F32)
     RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
     RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
     default: return hipErrorInvalidValue;
   }
 #undef RR_GEMM_CASE

@@ -96,7 +96,8 @@ enum GemmEpilogue {
   EPI_BIAS_GELU_BF16 = 1,  // C = bf16(gelu_erf(A W^T + b))
   EPI_BIAS_F32 = 2,        // C = f32(A W^T + b)
   EPI_BIAS_TANH_BF16 = 3,  // C = bf16(tanh(A W^T + b))
-  EPI_BIAS_RESID_F32 = 4   // C = f32(A W^T + b + R)
+  EPI_BIAS_RESID_F32 = 4,  // C = f32(A W^T + b + R)
+  EPI_BIAS_QGELU_BF16 = 5  // C = 16bit(quick_gelu(A W^T + b)), x * sigmoid(1.702 x)  (CLIP ViT MLP)
 };
 
 // A [M,Kd] bf16 (row stride lda), W [N,Kd] bf16 (row stride ldw), bias [N] f32 or null,
