@@ -86,7 +86,10 @@ typedef struct rr_config {
                                  forward; range +-65504 is ample for BERT activations, accumulation/residual/
                                  LayerNorm/softmax stay fp32 in both modes) */
   int32_t model_kind;         /* rr_model_kind: which reference reranker class the handle stands for */
-  int32_t reserved[5];
+  /* optional CLIP ViT image-feature producer (rr_encode_image); vit_layers = 0 => features come from the caller.
+     Defaults of FLMRVisionConfig (configuration_flmr.py:90-104): 12 layers, 12 heads, 3072, 224, 32; hidden =
+     vision_hidden, n_patches must equal (vit_image_size / vit_patch_size)^2, head dim 64. */
+  int32_t vit_layers, vit_heads, vit_intermediate, vit_image_size, vit_patch_size;
 } rr_config;
 
 /* reranker families */
@@ -165,6 +168,18 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
                float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
                int32_t* order_out, void* hip_stream);
 
+/* rr_encode_image: the frozen CLIP vision tower the rerankers call once per query
+ * (rerank_model.py:408-411,424-426 -> FLMRVisionModel.forward, modeling_flmr.py:1701-1757 -> CLIPVisionTransformer):
+ * patch convolution (stride = kernel, no bias) as an im2col GEMM, [class | patches] + position embedding,
+ * pre_layrnorm, vit_layers pre-LN blocks with quick-GELU MLPs.  Weights: the reference state_dict keys
+ * "context_vision_encoder.vision_model.vision_model.*" (required when cfg.vit_layers > 0; post_layernorm is not read).
+ *   pixel_values      : DEVICE float32 [B, 3, vit_image_size, vit_image_size]
+ *   image_cls_out     : DEVICE float32 [B, vision_hidden]            = last_hidden_state[:, 0] (no post_layernorm)
+ *   image_patches_out : DEVICE float32 [B, n_patches, vision_hidden] = hidden_states[-2][:, 1:]
+ * The outputs are exactly the image_cls / image_patches arguments of rr_forward / rr_forward_joint. */
+int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_cls_out, float* image_patches_out,
+                    void* hip_stream);
+
 /* rr_forward_joint: RerankModel.forward (the "softmax"/2-head variant, rerank_model.py:171-331) from the joint
  * sequence the caller assembled as the reference does (:204-224): joint_ids = cat(query_ids repeated K times,
  * context_ids[:, 2 : 2 - query_len]) [N,S], same for the mask.  Inside: token types 0, query_mask with instruction
@@ -208,7 +223,8 @@ int rr_get_profile(rr_handle h, rr_profile* out, int reset);
  * All pointers DEVICE.  bf16 tensors are uint16_t bit patterns.  Kd % 64 == 0, N % 4 == 0. */
 int rr_op_gemm_bf16(const uint16_t* A /*[M,Kd]*/, const uint16_t* W /*[N,Kd]*/, const float* bias /*[N]|NULL*/,
                     int M, int N, int Kd,
-                    int epilogue /*0: +bias -> bf16; 1: +bias, erf-GELU -> bf16; 2: +bias -> f32; 3: +bias, tanh -> bf16*/,
+                    int epilogue /*0: +bias -> bf16; 1: +bias, erf-GELU -> bf16; 2: +bias -> f32; 3: +bias, tanh -> bf16;
+                                   5: +bias, quick-GELU -> bf16*/,
                     void* out, void* hip_stream);
 /* out f32 [M,N] = A W^T + bias + resid */
 int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid /*[M,N]*/,

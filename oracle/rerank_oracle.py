@@ -69,6 +69,12 @@ class OracleConfig:
     cross_attn_len: int = 32               # transformer_mapping_cross_attention_length
     loss_fn: str = "BCE"                   # BCE | 2H_BCE | negative_sampling (utils.py:208-224)
     pos_weight: Optional[float] = None
+    # CLIP vision tower (FLMRVisionConfig defaults = openai/clip-vit-base-patch32, configuration_flmr.py:90-104)
+    vit_layers: int = 12
+    vit_heads: int = 12
+    vit_intermediate: int = 3072
+    vit_image_size: int = 224
+    vit_patch_size: int = 32
 
 
 # --------------------------------------------------------------------------- blocks
@@ -550,6 +556,87 @@ def recall_precision_at_k(ranked_ids: Sequence[Sequence], pos_ids: Sequence[Sequ
             prec[j] += s / k
     n = max(1, len(ranked_ids))
     return {"recall": [r / n for r in rec], "precision": [p / n for p in prec]}
+
+
+# --------------------------------------------------------------------------- CLIP vision tower
+VIT_PREFIX = "context_vision_encoder.vision_model.vision_model"   # FLMRVisionModel.vision_model = CLIPVisionModel
+VIT_LN_EPS = 1e-5                                                 # CLIPVisionConfig.layer_norm_eps
+
+
+def quick_gelu(x: Tensor) -> Tensor:
+    """CLIP's hidden_act "quick_gelu": x * sigmoid(1.702 x) (transformers activations.QuickGELUActivation)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def clip_vision_forward(cfg: OracleConfig, w: Dict[str, Tensor], pixel_values: Tensor, mm=None
+                        ) -> Tuple[Tensor, Tensor]:
+    """FLMRVisionModel.forward(pixel_values, output_hidden_states=True) (modeling_flmr.py:1701-1757) =
+    HF 4.38 CLIPVisionTransformer: Conv2d(3, Vh, kernel = stride = patch, bias=False) -> [class | patches] +
+    position_embedding -> pre_layrnorm -> pre-LN encoder layers (q scaled by dh^-0.5 after q_proj, quick-GELU MLP).
+    Returns what the rerankers take from it (rerank_model.py:408-411,424-426): last_hidden_state[:, 0]
+    (post_layernorm only touches pooler_output, which is not used) and hidden_states[-2][:, 1:]."""
+    v, ps, heads = VIT_PREFIX, cfg.vit_patch_size, cfg.vit_heads
+    B = pixel_values.shape[0]
+    Vh = cfg.vision_hidden
+    cols = F.unfold(pixel_values.to(torch.float32), kernel_size=ps, stride=ps).transpose(1, 2)   # [B, np, 3*ps*ps] (c,ky,kx)
+    Wp = w[f"{v}.embeddings.patch_embedding.weight"].reshape(Vh, -1)
+    patches = mm(cols, Wp) if mm is not None else cols @ Wp.t()
+    x = torch.cat([w[f"{v}.embeddings.class_embedding"].expand(B, 1, Vh), patches], dim=1)
+    x = x + w[f"{v}.embeddings.position_embedding.weight"][None, : x.shape[1]]
+    x = layer_norm(x, w, f"{v}.pre_layrnorm", VIT_LN_EPS)
+    states = [x]
+    for i in range(cfg.vit_layers):
+        l = f"{v}.encoder.layers.{i}"
+        h = layer_norm(x, w, f"{l}.layer_norm1", VIT_LN_EPS)
+        q = linear(h, w, f"{l}.self_attn.q_proj", mm)
+        k = linear(h, w, f"{l}.self_attn.k_proj", mm)
+        vv = linear(h, w, f"{l}.self_attn.v_proj", mm)
+        ctx = _MHA[-1](q, k, vv, heads, None)          # (q * dh^-0.5) k^T == q k^T / sqrt(dh)
+        x = x + linear(ctx, w, f"{l}.self_attn.out_proj", mm)
+        h = layer_norm(x, w, f"{l}.layer_norm2", VIT_LN_EPS)
+        x = x + linear(quick_gelu(linear(h, w, f"{l}.mlp.fc1", mm)), w, f"{l}.mlp.fc2", mm)
+        states.append(x)
+    return states[-1][:, 0], states[-2][:, 1:]
+
+
+def vit_weight_spec(cfg: OracleConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
+    Vh, Iv, ps, v = cfg.vision_hidden, cfg.vit_intermediate, cfg.vit_patch_size, VIT_PREFIX
+    s: List[Tuple[str, Tuple[int, ...], str]] = [
+        (f"{v}.embeddings.class_embedding", (Vh,), "e"),
+        (f"{v}.embeddings.patch_embedding.weight", (Vh, 3, ps, ps), "w"),
+        (f"{v}.embeddings.position_embedding.weight", (cfg.n_patches + 1, Vh), "e"),
+        (f"{v}.pre_layrnorm.weight", (Vh,), "g"), (f"{v}.pre_layrnorm.bias", (Vh,), "b")]
+    for i in range(cfg.vit_layers):
+        l = f"{v}.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s += [(f"{l}.self_attn.{n}.weight", (Vh, Vh), "w"), (f"{l}.self_attn.{n}.bias", (Vh,), "b")]
+        s += [(f"{l}.layer_norm1.weight", (Vh,), "g"), (f"{l}.layer_norm1.bias", (Vh,), "b"),
+              (f"{l}.mlp.fc1.weight", (Iv, Vh), "w"), (f"{l}.mlp.fc1.bias", (Iv,), "b"),
+              (f"{l}.mlp.fc2.weight", (Vh, Iv), "w"), (f"{l}.mlp.fc2.bias", (Vh,), "b"),
+              (f"{l}.layer_norm2.weight", (Vh,), "g"), (f"{l}.layer_norm2.bias", (Vh,), "b")]
+    return s
+
+
+def make_vit_weights(cfg: OracleConfig, seed: int = 0, hf_init: bool = False) -> Dict[str, Tensor]:
+    """Seeded synthetic CLIP-tower weights (same per-tensor generator scheme as make_weights, offset so the
+    two sets never share a stream)."""
+    w: Dict[str, Tensor] = {}
+    for idx, (name, shape, kind) in enumerate(vit_weight_spec(cfg)):
+        g = torch.Generator().manual_seed(seed * 1000003 + 500000 + idx)
+        if kind in ("w", "e"):
+            t = torch.randn(shape, generator=g) * 0.02
+        elif kind == "g":
+            t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = torch.zeros(shape) if hf_init else 0.05 * torch.randn(shape, generator=g)
+        w[name] = t
+    return w
+
+
+def make_pixel_values(cfg: OracleConfig, B: int, seed: int = 2022) -> Tensor:
+    """CLIP-normalised pixels are roughly N(0, 1.2) per channel; seeded stand-in."""
+    g = torch.Generator().manual_seed(seed + 11)
+    return 1.2 * torch.randn(B, 3, cfg.vit_image_size, cfg.vit_image_size, generator=g)
 
 
 # --------------------------------------------------------------------------- synthetic data

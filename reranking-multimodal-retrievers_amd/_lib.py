@@ -31,7 +31,8 @@ class RRConfig(C.Structure):
                                          "has_vision", "vision_hidden", "prefix_len", "n_patches", "map_layers",
                                          "cross_attn_len", "loss_kind")] + \
                [("pos_weight", C.c_float), ("device", C.c_int32), ("compute_dtype", C.c_int32),
-                ("model_kind", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("model_kind", C.c_int32), ("vit_layers", C.c_int32), ("vit_heads", C.c_int32),
+                ("vit_intermediate", C.c_int32), ("vit_image_size", C.c_int32), ("vit_patch_size", C.c_int32)]
 
 
 class RRProfile(C.Structure):
@@ -58,6 +59,7 @@ _SIGS = {
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
     "rr_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                              _P, _P, _P, _P, _P, _P]),
+    "rr_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "rr_forward_joint": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                    _P, _P, _P, _P, _P, _P]),
     "rr_forward_interaction": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,

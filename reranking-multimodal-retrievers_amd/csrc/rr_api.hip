@@ -124,6 +124,11 @@ struct rr_model {
   float* b_cemap = nullptr;
   float *ce_pos = nullptr, *ce_type = nullptr, *ce_emb_g = nullptr, *ce_emb_b = nullptr;
   float *cls1_w = nullptr, *cls1_b = nullptr, *cls2_w = nullptr, *cls2_b = nullptr;
+  // CLIP ViT (optional)
+  std::vector<LayerW> vit_layers;
+  bf16_t* vit_wpatch = nullptr;                             // [Vh, Kp] patch convolution, zero-padded to Kp
+  float *vit_cls = nullptr, *vit_pos = nullptr, *vit_pre_g = nullptr, *vit_pre_b = nullptr;
+  int vit_kp = 0;
 
   // workspace (grow-only)
   char* ws = nullptr;
@@ -270,6 +275,30 @@ void build_required(rr_model* m) {
     req(m, "transformer_mapping_output_linear.weight", {D, H});
     req(m, "transformer_mapping_output_linear.bias", {D});
   }
+  if (c.vit_layers > 0) {   // FLMRVisionModel.vision_model (CLIPVisionModel) .vision_model (CLIPVisionTransformer)
+    const int Vh = c.vision_hidden, Iv = c.vit_intermediate, ps = c.vit_patch_size;
+    const std::string v = "context_vision_encoder.vision_model.vision_model";
+    req(m, v + ".embeddings.class_embedding", {Vh});
+    req(m, v + ".embeddings.patch_embedding.weight", {Vh, 3, ps, ps});
+    req(m, v + ".embeddings.position_embedding.weight", {c.n_patches + 1, Vh});
+    req(m, v + ".pre_layrnorm.weight", {Vh});
+    req(m, v + ".pre_layrnorm.bias", {Vh});
+    for (int i = 0; i < c.vit_layers; ++i) {
+      const std::string l = v + ".encoder.layers." + std::to_string(i);
+      for (const char* n : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+        req(m, l + ".self_attn." + n + ".weight", {Vh, Vh});
+        req(m, l + ".self_attn." + n + ".bias", {Vh});
+      }
+      req(m, l + ".layer_norm1.weight", {Vh});
+      req(m, l + ".layer_norm1.bias", {Vh});
+      req(m, l + ".mlp.fc1.weight", {Iv, Vh});
+      req(m, l + ".mlp.fc1.bias", {Iv});
+      req(m, l + ".mlp.fc2.weight", {Vh, Iv});
+      req(m, l + ".mlp.fc2.bias", {Vh});
+      req(m, l + ".layer_norm2.weight", {Vh});
+      req(m, l + ".layer_norm2.bias", {Vh});
+    }
+  }
   const int Hc = c.ce_hidden, Ic = c.ce_intermediate;
   req(m, "cross_encoder_input_mapping.weight", {Hc, D});
   req(m, "cross_encoder_input_mapping.bias", {Hc});
@@ -356,6 +385,44 @@ int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross,
   return RR_OK;
 }
 
+// CLIPEncoderLayer: q/k/v fused with CLIP's q scaling (dh^-0.5 applied to q_proj's output, bias included) folded in
+int pack_vit_layer(rr_model* m, const std::string& l, int heads, int Vh, LayerW* L) {
+  const float qs = 1.0f / sqrtf((float)(Vh / heads));
+  const std::string a = l + ".self_attn";
+  RR_TRY(up_bf16(m, cat({&HT(m, a + ".q_proj.weight"), &HT(m, a + ".k_proj.weight"), &HT(m, a + ".v_proj.weight")}, qs), &L->wqkv));
+  RR_TRY(up_f32(m, cat({&HT(m, a + ".q_proj.bias"), &HT(m, a + ".k_proj.bias"), &HT(m, a + ".v_proj.bias")}, qs), &L->bqkv));
+  RR_TRY(up_bf16(m, HT(m, a + ".out_proj.weight"), &L->wo));
+  RR_TRY(up_f32(m, HT(m, a + ".out_proj.bias"), &L->bo));
+  RR_TRY(up_f32(m, HT(m, l + ".layer_norm1.weight"), &L->ln1g));
+  RR_TRY(up_f32(m, HT(m, l + ".layer_norm1.bias"), &L->ln1b));
+  RR_TRY(up_bf16(m, HT(m, l + ".mlp.fc1.weight"), &L->w1));
+  RR_TRY(up_f32(m, HT(m, l + ".mlp.fc1.bias"), &L->b1));
+  RR_TRY(up_bf16(m, HT(m, l + ".mlp.fc2.weight"), &L->w2));
+  RR_TRY(up_f32(m, HT(m, l + ".mlp.fc2.bias"), &L->b2));
+  RR_TRY(up_f32(m, HT(m, l + ".layer_norm2.weight"), &L->ln2g));
+  RR_TRY(up_f32(m, HT(m, l + ".layer_norm2.bias"), &L->ln2b));
+  return RR_OK;
+}
+
+int pack_vit(rr_model* m) {
+  const rr_config& c = m->cfg;
+  const int Vh = c.vision_hidden, Kd = 3 * c.vit_patch_size * c.vit_patch_size, Kp = (Kd + 63) / 64 * 64;
+  const std::string v = "context_vision_encoder.vision_model.vision_model";
+  m->vit_kp = Kp;
+  const std::vector<float>& wp = HT(m, v + ".embeddings.patch_embedding.weight");   // [Vh, 3*ps*ps] row-major
+  std::vector<float> padded((size_t)Vh * Kp, 0.f);
+  for (int r = 0; r < Vh; ++r) memcpy(&padded[(size_t)r * Kp], &wp[(size_t)r * Kd], (size_t)Kd * 4);
+  RR_TRY(up_bf16(m, padded, &m->vit_wpatch));
+  RR_TRY(up_f32(m, HT(m, v + ".embeddings.class_embedding"), &m->vit_cls));
+  RR_TRY(up_f32(m, HT(m, v + ".embeddings.position_embedding.weight"), &m->vit_pos));
+  RR_TRY(up_f32(m, HT(m, v + ".pre_layrnorm.weight"), &m->vit_pre_g));
+  RR_TRY(up_f32(m, HT(m, v + ".pre_layrnorm.bias"), &m->vit_pre_b));
+  m->vit_layers.resize(c.vit_layers);
+  for (int i = 0; i < c.vit_layers; ++i)
+    RR_TRY(pack_vit_layer(m, v + ".encoder.layers." + std::to_string(i), c.vit_heads, Vh, &m->vit_layers[i]));
+  return RR_OK;
+}
+
 // ---- workspace -------------------------------------------------------------------------------
 struct Bump {
   char* base;
@@ -377,6 +444,25 @@ struct Work {
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
   float *vp_out32, *t32, *vpre, *a32, *a32b, *cpre, *c32, *m32, *mo32;
 };
+
+// Workspace of the CLIP ViT over B images
+struct VitWork {
+  bf16_t *cols, *n16, *qkv, *ctx, *mid;
+  float *patch32, *xa, *xb;
+};
+size_t layout_vit(const rr_config& c, int kp, int B, char* base, VitWork* w) {
+  Bump b(base);
+  const size_t np = c.n_patches, R = (size_t)B * (np + 1), Vh = c.vision_hidden;
+  w->cols = b.take<bf16_t>((size_t)B * np * kp);
+  w->patch32 = b.take<float>((size_t)B * np * Vh);
+  w->xa = b.take<float>(R * Vh);
+  w->xb = b.take<float>(R * Vh);
+  w->n16 = b.take<bf16_t>(R * Vh);
+  w->qkv = b.take<bf16_t>(R * 3 * Vh);
+  w->ctx = b.take<bf16_t>(R * Vh);
+  w->mid = b.take<bf16_t>(R * c.vit_intermediate);
+  return (b.off + 255) & ~(size_t)255;
+}
 
 size_t imax(size_t a, size_t b) { return a > b ? a : b; }
 
@@ -624,6 +710,16 @@ int rr_create(const rr_config* cfg, rr_handle* out) {
         (c.li_dim * c.prefix_len / 2) % 64)
       return bad("bad vision configuration");
   }
+  if (c.vit_layers < 0) return bad("vit_layers < 0");
+  if (c.vit_layers > 0) {
+    if (c.model_kind != RR_MODEL_FULL_CONTEXT || !c.has_vision) return bad("the CLIP ViT needs a full-context model with has_vision");
+    if (c.vit_heads <= 0 || c.vision_hidden != c.vit_heads * 64) return bad("CLIP ViT head dim must be 64");
+    if (c.vit_intermediate <= 0 || c.vit_intermediate % 64 || c.vision_hidden > 2048) return bad("bad CLIP ViT widths");
+    if (c.vit_patch_size <= 0 || c.vit_image_size <= 0 || c.vit_image_size % c.vit_patch_size)
+      return bad("vit_image_size must be a multiple of vit_patch_size");
+    const int g = c.vit_image_size / c.vit_patch_size;
+    if (g * g != c.n_patches) return bad("n_patches must equal (vit_image_size / vit_patch_size)^2");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c.device < 0 || c.device >= ndev) {
     g_create_err = "no HIP device visible (librerank_mi355 has no CPU path)";
@@ -751,6 +847,7 @@ int rr_finalize_weights(rr_handle h) {
     RR_TRY(up_bf16(m, HT(m, "transformer_mapping_output_linear.weight"), &m->w_mout));
     RR_TRY(up_f32(m, HT(m, "transformer_mapping_output_linear.bias"), &m->b_mout));
   }
+  if (c.vit_layers > 0) RR_TRY(pack_vit(m));
   RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
   RR_TRY(up_f32(m, HT(m, "cross_encoder_input_mapping.bias"), &m->b_cemap));
   p = "reranker.bert_model";
@@ -774,6 +871,52 @@ int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len) {
   if (!h || n_pairs <= 0 || seq_len <= 0) return RR_ERR_BAD_ARG;
   Work w;
   return (int64_t)layout(h->cfg, n_pairs, n_pairs, seq_len, h->cfg.has_vision != 0, nullptr, &w);
+}
+
+int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_cls_out, float* image_patches_out,
+                    void* hip_stream) {
+  if (!h || !pixel_values || !image_cls_out || !image_patches_out) return fail(h, RR_ERR_BAD_ARG, "rr_encode_image: null argument");
+  rr_model* m = h;
+  const rr_config& c = m->cfg;
+  if (c.vit_layers <= 0) return fail(m, RR_ERR_UNSUPPORTED, "rr_encode_image: the handle was created without a CLIP ViT (vit_layers = 0)");
+  if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_encode_image before rr_finalize_weights");
+  if (B <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_encode_image: B=%d", B);
+  hipStream_t st = (hipStream_t)hip_stream;
+  RR_HIP(m, hipSetDevice(c.device));
+  const int Vh = c.vision_hidden, Iv = c.vit_intermediate, np = c.n_patches, T = np + 1, R = B * T, Kp = m->vit_kp;
+  const float eps = 1e-5f;   // CLIPVisionConfig.layer_norm_eps
+  VitWork w;
+  const size_t need = layout_vit(c, Kp, B, nullptr, &w);
+  RR_TRY(ensure_ws(m, need, st));
+  layout_vit(c, Kp, B, m->ws, &w);
+  m->last_stream = st;
+
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 4.0 * B * 3 * c.vit_image_size * c.vit_image_size + 2.0 * B * np * Kp,
+         rr_launch_vit_im2col(pixel_values, w.cols, B, c.vit_image_size, c.vit_patch_size, Kp, m->dt, st));
+  RR_GEMM(m, st, w.cols, Kp, m->vit_wpatch, nullptr, nullptr, 0, w.patch32, Vh, B * np, Vh, Kp, EPI_BIAS_F32, 4.0);
+  RR_RUN(m, st, RR_K_EMBED, 0.0, 8.0 * R * Vh,
+         rr_launch_vit_embed_ln(w.patch32, m->vit_cls, m->vit_pos, m->vit_pre_g, m->vit_pre_b, eps, R, T, Vh, w.xa, st));
+  float *x = w.xa, *y = w.xb;   // fp32 residual stream (pre-LN blocks: the stream itself is never normalised)
+  auto emit_patches = [&](const float* src) {
+    return hipMemcpy2DAsync(image_patches_out, (size_t)np * Vh * 4, src + Vh, (size_t)T * Vh * 4, (size_t)np * Vh * 4, B,
+                            hipMemcpyDeviceToDevice, st);
+  };
+  for (int l = 0; l < c.vit_layers; ++l) {
+    const LayerW& L = m->vit_layers[l];
+    if (l == c.vit_layers - 1) RR_RUN(m, st, RR_K_TAIL, 0.0, 8.0 * B * np * Vh, emit_patches(x));   // hidden_states[-2]
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 6.0 * R * Vh, rr_launch_layernorm(x, L.ln1g, L.ln1b, eps, R, Vh, nullptr, w.n16, m->dt, st));
+    RR_GEMM(m, st, w.n16, Vh, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Vh, R, 3 * Vh, Vh, EPI_BIAS_BF16, 2.0);
+    RR_RUN(m, st, RR_K_ATTENTION, 4.0 * B * (double)T * T * Vh, 2.0 * 4.0 * R * Vh,
+           rr_launch_attention(w.qkv, 3 * Vh, 1, 0, w.qkv + Vh, w.qkv + 2 * Vh, 3 * Vh, nullptr, B, c.vit_heads, T, T,
+                               w.ctx, Vh, m->dt, st));
+    RR_GEMM(m, st, w.ctx, Vh, L.wo, L.bo, x, Vh, y, Vh, R, Vh, Vh, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 6.0 * R * Vh, rr_launch_layernorm(y, L.ln2g, L.ln2b, eps, R, Vh, nullptr, w.n16, m->dt, st));
+    RR_GEMM(m, st, w.n16, Vh, L.w1, L.b1, nullptr, 0, w.mid, Iv, R, Iv, Vh, EPI_BIAS_QGELU_BF16, 2.0);
+    RR_GEMM(m, st, w.mid, Iv, L.w2, L.b2, y, Vh, x, Vh, R, Vh, Iv, EPI_BIAS_RESID_F32, 4.0);
+  }
+  RR_RUN(m, st, RR_K_TAIL, 0.0, 8.0 * B * Vh,
+         hipMemcpy2DAsync(image_cls_out, (size_t)Vh * 4, x, (size_t)T * Vh * 4, (size_t)Vh * 4, B, hipMemcpyDeviceToDevice, st));
+  return RR_OK;
 }
 
 int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,

@@ -114,5 +114,10 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
                                int heads, int Tq, int Tk, bf16_t* out, int out_stride, int dt,
                                hipStream_t st);
 
+// CLIP ViT front end: im2col of the stride = kernel patch convolution, and [class | patches] + position -> pre_layrnorm
+hipError_t rr_launch_vit_im2col(const float* px, bf16_t* out, int B, int IS, int ps, int Kp, int dt, hipStream_t st);
+hipError_t rr_launch_vit_embed_ln(const float* patches, const float* cls_emb, const float* pos, const float* gamma,
+                                  const float* beta, float eps, int rows, int T, int cols, float* o32, hipStream_t st);
+
 hipError_t rr_launch_layernorm(const float* x, const float* gamma, const float* beta, float eps,
                                int rows, int cols, float* out_f32, bf16_t* out_bf16, int dt, hipStream_t st);

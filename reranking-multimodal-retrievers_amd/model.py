@@ -46,6 +46,9 @@ def _get(cfg, name, default=None):
 FLMR_DEFAULTS = dict(vocab_size=30522, hidden=768, layers=12, heads=12, intermediate=3072, max_pos=512,
                      type_vocab=2, ln_eps=1e-12, li_dim=128, vision_hidden=768, prefix_len=32, n_patches=49,
                      map_layers=1, cross_attn_len=32)
+# CLIP ViT-B/32 vision tower (FLMRVisionConfig, configuration_flmr.py:90-104); vit_layers = 0 leaves the image
+# features to the caller (image_feature_fn / image_features=)
+VIT_DEFAULTS = dict(vit_layers=0, vit_heads=12, vit_intermediate=3072, vit_image_size=224, vit_patch_size=32)
 CE_DEFAULTS = dict(ce_hidden=768, ce_heads=12, ce_intermediate=3072)   # cross_encoder_config_base = bert-base-uncased
 
 
@@ -55,6 +58,9 @@ def make_arch(reranker_config=None, **overrides) -> dict:
     ... — monoBERT_pointwise.jsonnet:111-122) plus optional `arch` overrides for the FLMR side."""
     a = dict(FLMR_DEFAULTS)
     a.update(CE_DEFAULTS)
+    a.update(VIT_DEFAULTS)
+    if _get(reranker_config, "vision_encoder", False):     # run the CLIP tower inside the library
+        a["vit_layers"] = 12
     a.update(ce_layers=_get(reranker_config, "cross_encoder_num_hidden_layers", 1),
              ce_max_pos=_get(reranker_config, "cross_encoder_max_position_embeddings", 750),
              loss_fn=_get(reranker_config, "loss_fn", "BCE"),
@@ -121,6 +127,8 @@ def weight_spec(a: dict) -> List[tuple]:
             s += layer(f"transformer_mapping_network.layer.{i}", H, I, True)
         s += [("transformer_mapping_output_linear.weight", (D, H), "w"),
               ("transformer_mapping_output_linear.bias", (D,), "b")]
+    if a.get("vit_layers", 0) > 0:
+        s += vit_weight_spec(a)
     Hc, Ic = a["ce_hidden"], a["ce_intermediate"]
     s += [("cross_encoder_input_mapping.weight", (Hc, D), "w"), ("cross_encoder_input_mapping.bias", (Hc,), "b")]
     p = "reranker.bert_model"
@@ -131,6 +139,27 @@ def weight_spec(a: dict) -> List[tuple]:
         s += layer(f"{p}.encoder.layer.{i}", Hc, Ic, False)
     s += [("reranker.classifier1.weight", (1, Hc), "w"), ("reranker.classifier1.bias", (1,), "b"),
           ("reranker.classifier2.weight", (1, Hc), "w"), ("reranker.classifier2.bias", (1,), "b")]
+    return s
+
+
+VIT_PREFIX = "context_vision_encoder.vision_model.vision_model"   # FLMRVisionModel -> CLIPVisionModel -> transformer
+
+
+def vit_weight_spec(a: dict) -> List[tuple]:
+    """CLIP vision tower tensors under the reference's state_dict keys (modeling_flmr.py:1684-1757)."""
+    Vh, Iv, ps, v = a["vision_hidden"], a["vit_intermediate"], a["vit_patch_size"], VIT_PREFIX
+    s = [(f"{v}.embeddings.class_embedding", (Vh,), "e"),
+         (f"{v}.embeddings.patch_embedding.weight", (Vh, 3, ps, ps), "w"),
+         (f"{v}.embeddings.position_embedding.weight", (a["n_patches"] + 1, Vh), "e"),
+         (f"{v}.pre_layrnorm.weight", (Vh,), "g"), (f"{v}.pre_layrnorm.bias", (Vh,), "b")]
+    for i in range(a["vit_layers"]):
+        l = f"{v}.encoder.layers.{i}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s += [(f"{l}.self_attn.{n}.weight", (Vh, Vh), "w"), (f"{l}.self_attn.{n}.bias", (Vh,), "b")]
+        s += [(f"{l}.layer_norm1.weight", (Vh,), "g"), (f"{l}.layer_norm1.bias", (Vh,), "b"),
+              (f"{l}.mlp.fc1.weight", (Iv, Vh), "w"), (f"{l}.mlp.fc1.bias", (Iv,), "b"),
+              (f"{l}.mlp.fc2.weight", (Vh, Iv), "w"), (f"{l}.mlp.fc2.bias", (Vh,), "b"),
+              (f"{l}.layer_norm2.weight", (Vh,), "g"), (f"{l}.layer_norm2.bias", (Vh,), "b")]
     return s
 
 
@@ -180,6 +209,8 @@ class RerankEngine:
         if mk not in L.MODEL_KINDS:
             raise ValueError(f"model_kind must be one of {sorted(L.MODEL_KINDS)}, got {mk!r}")
         c.model_kind = L.MODEL_KINDS[mk]
+        for k, v in VIT_DEFAULTS.items():
+            setattr(c, k, int(arch.get(k, v)))
         c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         L.check(self.lib.rr_create(C.byref(c), C.byref(h)), None, "rr_create")
@@ -268,6 +299,23 @@ class RerankEngine:
                                     L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores), L.ptr(order),
                                     stream), self.h, "rr_forward")
         return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
+
+    def encode_image(self, pixel_values: torch.Tensor):
+        """CLIP vision tower (rr_encode_image): pixel_values [B,3,IS,IS] -> (last_hidden_state[:,0] [B,Vh],
+        hidden_states[-2][:,1:] [B,np,Vh]) — what rerank_model.py:408-411,424-426 takes from context_vision_encoder."""
+        a, dev = self.arch, self.device
+        IS = int(a.get("vit_image_size", 224))
+        if pixel_values.dim() == 5:                                   # [B,1,3,H,W] as the datasets deliver it
+            pixel_values = pixel_values.reshape(-1, *pixel_values.shape[2:])
+        if tuple(pixel_values.shape[1:]) != (3, IS, IS):
+            raise AssertionError(f"pixel_values must be [B,3,{IS},{IS}], got {tuple(pixel_values.shape)}")
+        px = pixel_values.to(device=dev, dtype=torch.float32).contiguous()
+        B = px.shape[0]
+        cls = torch.empty((B, a["vision_hidden"]), dtype=torch.float32, device=dev)
+        patches = torch.empty((B, a["n_patches"], a["vision_hidden"]), dtype=torch.float32, device=dev)
+        L.check(self.lib.rr_encode_image(self.h, L.ptr(px), B, L.ptr(cls), L.ptr(patches),
+                                         torch.cuda.current_stream(dev).cuda_stream), self.h, "rr_encode_image")
+        return cls, patches
 
     def forward_joint(self, joint_input_ids: torch.Tensor, joint_attention_mask: torch.Tensor, Bq: int, K: int,
                       query_len: int, image_cls: torch.Tensor, image_patches: torch.Tensor,
@@ -376,8 +424,10 @@ class FullContextRerankModel(torch.nn.Module):
       `arch`            – dict overriding the FLMR/BERT architecture defaults (tests use tiny shapes)
       `tokenizer`       – any HF-style tokenizer (encode/decode/batch_encode_plus); required only for the
                           text call signature (no vocab file exists in the build environment)
-      `image_feature_fn`– callable pixel_values[Bq,3,224,224] -> (cls [Bq,Vh], patches [Bq,np,Vh]); required only
-                          when `query_pixel_values` is passed (the CLIP ViT is upstream of the path)
+      `vision_encoder`  – True: run the CLIP ViT-B/32 tower inside the library (rr_encode_image; the state_dict must
+                          then hold `context_vision_encoder.vision_model.vision_model.*`)
+      `image_feature_fn`– otherwise a callable pixel_values[Bq,3,224,224] -> (cls [Bq,Vh], patches [Bq,np,Vh]) that
+                          wraps the reference-side `context_vision_encoder`
       `text_only`       – build without the vision weights (`text_only` module of the reference configs)
     """
 
@@ -443,9 +493,13 @@ class FullContextRerankModel(torch.nn.Module):
         dev = self.engine.device
         cls = patches = None
         if not text_only:
-            if self.image_feature_fn is None:
-                raise NotImplementedError("query_pixel_values given but config.image_feature_fn (CLIP ViT) is not set")
-            cls, patches = self.image_feature_fn(query_pixel_values)
+            if self.image_feature_fn is not None:
+                cls, patches = self.image_feature_fn(query_pixel_values)
+            elif self.engine.arch.get("vit_layers", 0) > 0:
+                cls, patches = self.engine.encode_image(query_pixel_values)
+            else:
+                raise NotImplementedError("query_pixel_values given but neither config.vision_encoder nor "
+                                          "config.image_feature_fn (CLIP ViT) is set")
         return self.forward_ids(enc["input_ids"].to(dev), enc["attention_mask"].to(dev),
                                 enc["token_type_ids"].to(dev), num_negative_examples, cls, patches,
                                 labels if labels else None)
@@ -535,9 +589,13 @@ class RerankModel(torch.nn.Module):
         if image_features is not None:
             cls, patches = image_features
         else:
-            if self.image_feature_fn is None:
-                raise NotImplementedError("query_pixel_values given but config.image_feature_fn (CLIP ViT) is not set")
-            cls, patches = self.image_feature_fn(query_pixel_values)
+            if self.image_feature_fn is not None:
+                cls, patches = self.image_feature_fn(query_pixel_values)
+            elif self.engine.arch.get("vit_layers", 0) > 0:
+                cls, patches = self.engine.encode_image(query_pixel_values)
+            else:
+                raise NotImplementedError("query_pixel_values given but neither config.vision_encoder nor "
+                                          "config.image_feature_fn (CLIP ViT) is set")
         r = self.engine.forward_joint(joint_ids, joint_am, Bq, K, ql, cls, patches, self.instruction_token_id, **kw)
         out = RerankOutput(loss=r["loss"], logits=r["logits"].view(N, 1))
         for k in ("scores", "order", "logits2"):

@@ -214,6 +214,44 @@ def run_rerankmodel_case(outdir, name="rm_tiny"):
                         loss=np.array(loss_hf.item(), dtype=np.float32), oracle_vs_hf=np.array([d_logit, d_loss]))
 
 
+VIT_CASES = {
+    # name: (cfg kwargs, B)   — the CLIP vision tower the rerankers call once per query (rerank_model.py:408-426)
+    "vit_tiny": (dict(vision_hidden=128, n_patches=16, vit_layers=3, vit_heads=2, vit_intermediate=256,
+                      vit_image_size=64, vit_patch_size=16), 3),
+    "vit_p14": (dict(vision_hidden=128, n_patches=16, vit_layers=2, vit_heads=2, vit_intermediate=256,
+                     vit_image_size=56, vit_patch_size=14), 2),           # 3*14*14 = 588: K not a multiple of 64
+    "vit_b32": (dict(), 2),                                                # openai/clip-vit-base-patch32 shape
+}
+
+
+def run_vit_case(name, outdir):
+    """Stock HF CLIPVisionModel with the seeded weights; pixel values are regenerated from the seed by the tests."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    kw, B = VIT_CASES[name]
+    cfg = O.OracleConfig(**kw)
+    w = O.make_vit_weights(cfg, seed=5)
+    hc = CLIPVisionConfig(hidden_size=cfg.vision_hidden, intermediate_size=cfg.vit_intermediate,
+                          num_hidden_layers=cfg.vit_layers, num_attention_heads=cfg.vit_heads,
+                          image_size=cfg.vit_image_size, patch_size=cfg.vit_patch_size, hidden_act="quick_gelu",
+                          layer_norm_eps=1e-5, attn_implementation="eager")
+    m = CLIPVisionModel(hc).eval()
+    sd = m.state_dict()
+    pref = "vision_model." if next(iter(sd)).startswith("vision_model.") else ""   # transformers 4.x vs 5.x key layout
+    new = {k: w.get(O.VIT_PREFIX + "." + k[len(pref):], t) for k, t in sd.items()}
+    assert sum(O.VIT_PREFIX + "." + k[len(pref):] in w for k in sd) == len(w)
+    m.load_state_dict(new)
+    px = O.make_pixel_values(cfg, B, seed=2022)
+    with torch.no_grad():
+        out = m(pixel_values=px, output_hidden_states=True)
+        cls_hf, pat_hf = out.last_hidden_state[:, 0], out.hidden_states[-2][:, 1:]
+        c, p_ = O.clip_vision_forward(cfg, w, px)
+    d = [(c - cls_hf).abs().max().item(), (p_ - pat_hf).abs().max().item()]
+    print(f"[{name}] oracle-vs-HF: cls {d[0]:.3e} patches {d[1]:.3e}")
+    np.savez_compressed(os.path.join(outdir, f"{name}.npz"), cfg_json=np.array(repr(kw)), B=B, weight_seed=5,
+                        pixel_seed=2022, pixel_checksum=np.array(px.double().sum().item()),
+                        image_cls=cls_hf.numpy(), image_patches=pat_hf.numpy(), oracle_vs_hf=np.array(d))
+
+
 INTERACTION_CASES = {
     # name: (cfg kwargs, Bq, K, Lq, Lc, mores, loss)
     "int_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
@@ -309,7 +347,7 @@ def run_case(name, outdir):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny"]))
+    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny"] + list(VIT_CASES)))
     a = ap.parse_args()
     torch.set_num_threads(8)
     for nm in a.which.split(","):
@@ -317,5 +355,7 @@ if __name__ == "__main__":
             run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)))
         elif nm in INTERACTION_CASES:
             run_interaction_case(nm, os.path.dirname(os.path.abspath(__file__)))
+        elif nm in VIT_CASES:
+            run_vit_case(nm, os.path.dirname(os.path.abspath(__file__)))
         else:
             run_case(nm, os.path.dirname(os.path.abspath(__file__)))

@@ -117,3 +117,20 @@ def test_interaction_oracle_matches_golden(name):
     np.testing.assert_allclose(out.logits.numpy(), z["logits"], atol=2e-5, rtol=0)
     assert abs(out.loss.item() - float(z["loss"])) < 2e-5
     assert z["oracle_vs_hf"][0] < 1e-5
+
+
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_p14", "vit_b32"])
+def test_vision_tower_oracle_matches_golden(name):
+    """CLIP vision tower restatement vs the stock-HF CLIPVisionModel outputs committed as goldens."""
+    import ast, os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg_json"])))
+    w = O.make_vit_weights(cfg, seed=int(z["weight_seed"]))
+    px = O.make_pixel_values(cfg, int(z["B"]), seed=int(z["pixel_seed"]))
+    assert abs(px.double().sum().item() - float(z["pixel_checksum"])) < 1e-6
+    with torch.no_grad():
+        c, p = O.clip_vision_forward(cfg, w, px)
+    np.testing.assert_allclose(c.numpy(), z["image_cls"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(p.numpy(), z["image_patches"], atol=5e-5, rtol=0)
+    assert z["oracle_vs_hf"].max() < 5e-5
