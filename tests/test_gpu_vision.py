@@ -82,7 +82,7 @@ def test_pixels_to_logits_through_module():
     out = m.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), K - 1, cls, pat)
     with torch.no_grad():
         oc, op = O.clip_vision_forward(cfg, w, px)
-        ref = O.full_context_forward(cfg, w, ids, am, tt, K - 1, oc, op)
+        ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, oc, op)
     d = (out.logits.cpu().reshape(-1) - ref.logits.reshape(-1)).abs().max().item()
     print(f"pixels->logits |dlogit| vs fp32 oracle {d:.2e}")
     assert d <= 2e-3
