@@ -270,7 +270,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __res
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
         if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
         if (EPI == EPI_BIAS_RESID_F32) {
           const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
           v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
@@ -411,7 +410,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
         if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
         if constexpr (F32_OUT) acc[nt][mt] = f32x4{v0, v1, v2, v3};
         else pk[nt][mt] = make_uint2(pack2<DT>(v0, v1), pack2<DT>(v2, v3));
       }
@@ -809,8 +807,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
           if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
           acc[q][nt][mt] = f32x4{v0, v1, v2, v3};
         }
       }
@@ -901,8 +897,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
           if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
           if (EPI == EPI_BIAS_RESID_F32) {
             const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
             v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;

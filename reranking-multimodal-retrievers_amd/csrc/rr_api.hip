@@ -1290,8 +1290,8 @@ int rr_set_op_dtype(int dt) {
 int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue,
                     void* out, void* hip_stream) {
   if (!A || !W || !out) return RR_ERR_BAD_ARG;
-  if (epilogue < 0 || epilogue > 3) return RR_ERR_BAD_ARG;
-  const int epi_map[4] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32, EPI_BIAS_TANH_BF16};
+  if (epilogue < 0 || epilogue > 5 || epilogue == 4) return RR_ERR_BAD_ARG;   // 4 (residual) has its own entry point
+  const int epi_map[6] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32, EPI_BIAS_TANH_BF16, -1, EPI_BIAS_QGELU_BF16};
   hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, nullptr, 0, out, N, M, N, Kd, epi_map[epilogue], g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
