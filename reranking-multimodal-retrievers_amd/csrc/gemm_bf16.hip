@@ -621,12 +621,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ 
 // stay in flight instead of one drained 64-KiB tile (tools/dma_probe.hip: 66 vs 53 GB/s per CU).  Every K-tile
 // is 4 phases, one output quadrant (64x32 per wave, 16 MFMAs) each: (A0,B0) (A0,B1) (A1,B1) (A1,B0); the
 // fragments a phase needs are read from LDS during the PREVIOUS phase, behind that phase's MFMAs.
-//   phase p of tile t:  [ds_read fragments for the next phase] [DMA half-tile 4(t+2)+p] [16 MFMAs]
-//                       [s_waitcnt vmcnt(N): the half-tiles the NEXT phase reads have landed] [lgkmcnt(0)] [s_barrier]
+//   phase:  [ds_read fragments for the next 8-MFMA block] [DMA of a half-tile whose slot is free] [8 MFMAs] x 2
+//   two sync points per K-tile (X after p1, Y after p3): [s_waitcnt vmcnt(N)] [lgkmcnt(0)] [s_barrier]
 // RAW: every wave waits for its own DMA pieces before the barrier that precedes their first ds_read.
-// WAR: a slot read in phase p is refilled only after barrier(p).  N counts exactly the DMA instructions issued
-// after the needed half-tile (2 per half-tile per wave), so the wait is exact in the tail as well.
-template <int EPI, bool LDS_EPI, int DT>
+// WAR: a slot is refilled only after the barrier that follows its last read.  N counts exactly the DMA instructions
+// issued after the needed half-tile (2 per half-tile per wave), so the wait is exact in the tail as well.
+template <int EPI, bool LDS_EPI, int DT, bool DIAG = false>
 __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ A, int lda,
                                                      const bf16_t* __restrict__ W, int ldw,
                                                      const float* __restrict__ bias,
@@ -634,7 +634,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                      int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
                                                      int stagger_unit) {
-  if (stagger_unit > 0) start_stagger(256, stagger_unit);
+  if (stagger_unit > 0 && stagger_unit < 60) start_stagger(256, stagger_unit);
+  if (stagger_unit == 63) lda = 0;                          // diagnostic: every A row is row 0 (cache-resident A; wrong results)
+  if (stagger_unit == 62) { lda = 0; ldw = 0; }             // diagnostic: A and W cache-resident
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -676,9 +678,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   auto wait_half = [&](int h_need, int h_last) {
     if (h_need >= H) return;
     const int after = h_last - h_need;                        // half-tiles issued after the needed one
-    if (after >= 5) wait_vmcnt<10>();
-    else if (after == 4) wait_vmcnt<8>();
-    else if (after == 3) wait_vmcnt<6>();
+    if (after >= 3) wait_vmcnt<6>();
     else if (after == 2) wait_vmcnt<4>();
     else if (after == 1) wait_vmcnt<2>();
     else wait_vmcnt<0>();
@@ -716,70 +716,129 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
       acc[Q][nt][mt] = mfma16<DT>(BF[nt], AF[mt], acc[Q][nt][mt]);
 #define RR_SBAR() __builtin_amdgcn_sched_barrier(0)
-#define RR_PHASE_END(g_need, g_last)                     \
-  RR_SBAR();                                             \
-  wait_half(g_need, g_last);                             \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-  __builtin_amdgcn_s_barrier();                          \
-  RR_SBAR();
 
   // ---- prologue: half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3}); first fragments of tile 0
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
   if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
-  const int g_pro = min(H - 1, 6);
-  wait_half(2, g_pro);                                      // A0(0), B0(0), B1(0) landed (my pieces)
+  wait_half(3, min(H - 1, 6));                              // all of tile 0 landed (my pieces)
   __builtin_amdgcn_s_barrier();
   stamp(stamps, 1);
   read_a(lds + 0 * HALF, 0, AF0);
   read_b(lds + 1 * HALF, 0, B0K0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1]));
 
-  for (int t = 0; t < nk; ++t) {
-    const char* sl = lds + (t & 1) * 4 * HALF;               // this tile's slots: +0 A0, +1 B0, +2 B1, +3 A1
-    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;         // next tile's
-    // ---- p0: quadrant (A0, B0)
-    read_a(sl + 0 * HALF, 1, AF1);
-    read_b(sl + 1 * HALF, 1, B0K1);
-    RR_SBAR();
-    RR_BLK(0, AF0, B0K0)
-    RR_SBAR();
-    read_b(sl + 2 * HALF, 0, B1K0);
-    if (4 * (t + 1) + 3 < H) RR_DMA(t + 1, 3)                // refill: A1 of the next tile (its slot was freed in p2(t-1))
-    RR_SBAR();
-    RR_BLK(0, AF1, B0K1)
-    RR_PHASE_END(4 * t + 3, min(H - 1, 4 * (t + 1) + 3))    // A1(t) landed
-    // ---- p1: quadrant (A0, B1)
-    read_b(sl + 2 * HALF, 1, B1K1);
-    RR_SBAR();
-    RR_BLK(1, AF0, B1K0)
-    RR_SBAR();
-    read_a(sl + 3 * HALF, 0, AF0);
-    if (t + 2 < nk) RR_DMA(t + 2, 0)                         // slot A0 (free since barrier p0)
-    RR_SBAR();
-    RR_BLK(1, AF1, B1K1)
-    RR_PHASE_END(H, 0)                                       // p2 reads A1(t) only: already landed
-    // ---- p2: quadrant (A1, B1)
-    read_a(sl + 3 * HALF, 1, AF1);
-    RR_SBAR();
-    RR_BLK(3, AF0, B1K0)
-    RR_SBAR();
-    if (t + 2 < nk) RR_DMA(t + 2, 1)                         // slot B0 (free since barrier p0)
-    RR_SBAR();
-    RR_BLK(3, AF1, B1K1)
-    RR_PHASE_END(4 * (t + 1) + 1, min(H - 1, 4 * (t + 2) + 1))   // A0(t+1), B0(t+1) landed
-    // ---- p3: quadrant (A1, B0)
-    RR_BLK(2, AF0, B0K0)
-    RR_SBAR();
-    if (t + 1 < nk) {
-      read_a(sn + 0 * HALF, 0, AF0);
-      read_b(sn + 1 * HALF, 0, B0K0);
-    }
-    if (t + 2 < nk) RR_DMA(t + 2, 2)                         // slot B1 (free since barrier p1)
-    RR_SBAR();
-    RR_BLK(2, AF1, B0K1)
-    RR_PHASE_END(4 * (t + 1) + 2, min(H - 1, 4 * (t + 2) + 2))   // B1(t+1) landed
+  // Diagnostic build (DIAG): per-wave s_memtime marks inside every phase, summed over the loop and written to
+  // stamps[block][8 + wave*8 + k]; the marks are read only after the phase's own lgkmcnt(0), so they add no wait.
+  unsigned long long dg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tmk[9];
+#define RR_MARK(k) { if constexpr (DIAG) { RR_SBAR(); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); RR_SBAR(); } }
+#define RR_ACC(base, n)                                                                       \
+  {                                                                                           \
+    if constexpr (DIAG) {                                                                     \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) dg[(base) + k_] += tmk[k_ + 1] - tmk[k_]; \
+    }                                                                                         \
   }
+  // sync point with marks m0 (before), m0+1 (after the vmcnt wait), m0+2 (after lgkmcnt(0)), m0+3 (after the barrier).
+  // In the steady state the wait is a literal (no scalar branch cascade in the loop body).
+#define RR_SYNC(STEADY, NLIT, g_need, g_last, m0)        \
+  {                                                      \
+    RR_SBAR();                                           \
+    RR_MARK(m0)                                          \
+    if (STEADY) wait_vmcnt<NLIT>();                      \
+    else wait_half(g_need, g_last);                      \
+    RR_MARK((m0) + 1)                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    RR_MARK((m0) + 2)                                    \
+    __builtin_amdgcn_s_barrier();                        \
+    RR_SBAR();                                           \
+    RR_MARK((m0) + 3)                                    \
+  }
+
+  // Two barriers per K-tile.  X (end of p1): A0/B0 of the next tile have landed and every wave is done with this
+  // tile's A0, B0, B1 slots; Y (end of p3): B1/A1 of the next tile have landed and every wave is done with this tile's
+  // A1 slot.  p0 and p2 end without a barrier: what they hand to p1 / p3 was covered by the previous Y / X.  (Four
+  // barriers, one per phase, cost 17 % more main-loop cycles.)  Refills: p0 A1(t+1); p2 A0(t+2), B0(t+2); p3 B1(t+2) —
+  // the g order the counted waits rely on.  Measured and NOT better: one barrier per tile (the refill window shrinks
+  // to one tile and the drained DMA sets the pace), an LDS arrive/poll counter instead of s_barrier (s_barrier itself
+  // is ~36 cycles, tools/barrier_probe.hip), one 1-KiB piece per 8-MFMA block instead of pairs (a piece costs its wave
+  // ~60 cycles wherever it sits), all pieces moved by the younger wave of each SIMD pair under EXEC masking (-10 %).
+  // RR_TILE(1) is the steady state (t <= nk-3): every refill exists and the vmcnt waits are literals, so the body is
+  // straight-line code; RR_TILE(0) handles the last two tiles with the general guards.
+#define RR_TILE(STEADY)                                                                                    \
+  {                                                                                                        \
+    const char* sl = lds + (t & 1) * 4 * HALF;               /* this tile's slots: +0 A0, +1 B0, +2 B1, +3 A1 */ \
+    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;         /* next tile's */                              \
+    const bool d1 = ((STEADY) || t + 1 < nk) && !no_dma, d2 = ((STEADY) || t + 2 < nk) && !no_dma;          \
+    /* ---- p0: quadrant (A0, B0) */                                                                        \
+    RR_MARK(0)                                                                                             \
+    read_a(sl + 0 * HALF, 1, AF1);                                                                         \
+    read_b(sl + 1 * HALF, 1, B0K1);                                                                        \
+    RR_SBAR();                                                                                             \
+    RR_BLK(0, AF0, B0K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(1)                                                                                             \
+    read_b(sl + 2 * HALF, 0, B1K0);                                                                        \
+    if (d1) RR_DMA(t + 1, 3)                                 /* A1 of the next tile (slot free since Y(t-1)) */ \
+    RR_SBAR();                                                                                             \
+    RR_MARK(2)                                                                                             \
+    RR_BLK(0, AF1, B0K1)                                                                                   \
+    RR_SBAR();                                                                                             \
+    /* ---- p1: quadrant (A0, B1) */                                                                        \
+    RR_MARK(3)                                                                                             \
+    read_b(sl + 2 * HALF, 1, B1K1);                                                                        \
+    RR_SBAR();                                                                                             \
+    RR_BLK(1, AF0, B1K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(4)                                                                                             \
+    read_a(sl + 3 * HALF, 0, AF0);                                                                         \
+    RR_SBAR();                                                                                             \
+    RR_BLK(1, AF1, B1K1)                                                                                   \
+    RR_SYNC(STEADY, 4, 4 * (t + 1) + 1, min(H - 1, 4 * (t + 1) + 3), 5)   /* X: A0(t+1), B0(t+1) landed */    \
+    RR_ACC(0, 8)                                                                                           \
+    /* ---- p2: quadrant (A1, B1) */                                                                        \
+    RR_MARK(0)                                                                                             \
+    read_a(sl + 3 * HALF, 1, AF1);                                                                         \
+    if (d2) RR_DMA(t + 2, 0)                                 /* slots A0, B0 (free since X) */               \
+    RR_SBAR();                                                                                             \
+    RR_BLK(3, AF0, B1K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    if (d2) RR_DMA(t + 2, 1)                                                                               \
+    RR_SBAR();                                                                                             \
+    RR_BLK(3, AF1, B1K1)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(1)                                                                                             \
+    /* ---- p3: quadrant (A1, B0) */                                                                        \
+    RR_BLK(2, AF0, B0K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    if ((STEADY) || t + 1 < nk) {                                                                          \
+      read_a(sn + 0 * HALF, 0, AF0);                                                                       \
+      read_b(sn + 1 * HALF, 0, B0K0);                                                                      \
+    }                                                                                                      \
+    if (d2) RR_DMA(t + 2, 2)                                 /* slot B1 (free since X) */                    \
+    RR_SBAR();                                                                                             \
+    RR_BLK(2, AF1, B0K1)                                                                                   \
+    RR_SYNC(STEADY, 6, 4 * (t + 1) + 3, min(H - 1, 4 * (t + 2) + 2), 2)   /* Y: B1(t+1), A1(t+1) landed */    \
+    /* The next tile's first fragments are complete here (lgkmcnt(0) above).  Tell the compiler: otherwise it    \
+       treats them as pending across the back edge and puts lgkmcnt(0) behind the six ds_reads that open p0. */  \
+    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1])); \
+    RR_ACC(8, 5)                                                                                           \
+  }
+  const bool no_dma = DIAG && stagger_unit == 61;            // diagnostic: main loop without refills (wrong results)
+  int t = 0;
+  for (; t < nk - 2; ++t) RR_TILE(1)
+  for (; t < nk; ++t) RR_TILE(0)
+#undef RR_TILE
+  if constexpr (DIAG) {
+    if (stamps && lane == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned long long* o = stamps + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 16;
+      for (int k = 0; k < 13; ++k) o[k] = dg[k];
+    }
+  }
+#undef RR_SYNC
+#undef RR_MARK
+#undef RR_ACC
 #undef RR_DMA
-#undef RR_PHASE_END
 #undef RR_BLK
 #undef RR_SBAR
   wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
@@ -911,6 +970,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 }
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
+int g_variant = -1;                      // tuning override (rr_set_gemm_variant); -1: shape heuristic
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 
@@ -936,6 +996,15 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
                        tiles_n, nwg, stamps, ln, nwg > 512 ? g_stagger : 0);                                                             \
     break;                                                                                                    \
+  }
+  if (g_variant == 13) {   // diagnostic timeline build (tools/bench_gemm.py --timeline): bf16, bias -> 16-bit only
+    if (!LDS_EPI || DT != 0 || epilogue != EPI_BIAS_BF16) return hipErrorInvalidValue;
+    auto kern = gemm_kernel_h<EPI_BIAS_BF16, true, 0, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, tiles_n, nwg,
+                       stamps, ln, g_stagger);
+    return hipGetLastError();
   }
   switch (epilogue) {
     RR_GEMM_CASE(EPI_BIAS_BF16)
@@ -1025,13 +1094,12 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   return hipGetLastError();
 }
 
-int g_variant = -1;   // tuning override: RR_GEMM_VARIANT=0..3 (unset: shape heuristic)
 
 }  // namespace
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 12) return -1;
+  if (v < -1 || v > 13) return -1;
   g_variant = v;
   return 0;
 }
@@ -1104,7 +1172,8 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
     case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-    case 12: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 12:
+    case 13: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     default: return hipErrorInvalidValue;
   }
