@@ -229,6 +229,14 @@ int rr_op_gemm_bf16(const uint16_t* A /*[M,Kd]*/, const uint16_t* W /*[N,Kd]*/, 
 /* out f32 [M,N] = A W^T + bias + resid */
 int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid /*[M,N]*/,
                          int M, int N, int Kd, float* out, void* hip_stream);
+/* The LayerNorm-statistics dataflow the layers use between blocks: rr_op_layernorm_stats writes the 16-bit normalised
+ * rows (and optionally the fp32 ones) plus stats[row] = (mean, rstd); rr_op_gemm_ln_resid_f32 then forms its residual
+ * as (x - mean) * rstd * gamma + beta from the LayerNorm's INPUT x:  out = A W^T + bias + LN(x). */
+int rr_op_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                          float* out_f32 /*|NULL*/, uint16_t* out_bf16, float* stats /*[rows,2]*/, void* hip_stream);
+int rr_op_gemm_ln_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* x /*[M,N]*/,
+                            const float* stats /*[M,2]*/, const float* gamma /*[N]*/, const float* beta /*[N]*/, int M,
+                            int N, int Kd, float* out, void* hip_stream);
 /* softmax(q k^T + key_bias) v per head (head dim 64; q is expected pre-scaled by 1/sqrt(64)).
  * q row (b,t): q + ((b / q_batch_div) * Tq + t) * q_stride + head*64 ; k,v row (b,t): (b*Tk + t) * kv_stride + head*64;
  * key_bias f32 [B,Tk] additive (0 = attend, -1e30 = masked) or NULL. */

@@ -16,7 +16,14 @@ LIB = os.path.join(HERE, "librerank_mi355.so")
 SOURCES = ["rr_api.hip", "gemm_bf16.hip", "attention_bf16.hip", "elementwise.hip", "head.hip"]
 HEADERS = [os.path.join(CSRC, "rr_common.h"), os.path.join(os.path.dirname(HERE), "include", "rerank_mi355.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: no compiler-formed v_pk_*_f32.  With SLP on, the LayerNorm-residual epilogue of the 128x128 GEMM
+# (two workgroups per CU) came out as v_pk_add/mul/fma_f32 directly behind the s_waitcnt of the loads they read, and
+# on gfx950 lanes 48-63 of the low register of a pair were intermittently stale (residual term lost on 16 rows x 1
+# column of a few tiles per launch, run-to-run different; tools/layer_determinism.py, tests/test_gpu_ops.py::
+# test_ln_residual_gemm_is_reproducible_and_matches_materialised_residual).  Scalar f32 code is exact; cost 0.7 % of
+# the bench step.  Hand-written 2-wide vector code (attention row sum) only touches VALU-produced values.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
+         *os.environ.get("RR_HIPCC_EXTRA", "").split()]          # RR_HIPCC_EXTRA: A/B experiments only
 # per-file extras: the attention softmax has no NaNs by construction; without IEEE-mode canonicalisation its 32-way row
 # max is 16 v_max3_f32 instead of 54 instructions
 EXTRA = {"attention_bf16.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
                                                              void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                              int tiles_n, int nwg, unsigned long long* stamps,
                                                              int stagger_unit, LnResid ln) {
-  if (stagger_unit > 0) start_stagger(256, stagger_unit);
+  if (stagger_unit > 0 && stagger_unit < 60) start_stagger(256, stagger_unit);
   stamp(stamps, 0);
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -317,28 +317,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  const bf16_t* a_src[PA];
-  const bf16_t* w_src[PW];
+  // per-piece source = scalar base (A or W, advanced by k0) + a 32-bit per-lane byte offset that lives in ONE VGPR for
+  // the whole kernel: nothing rewrites an address register behind an LDS-DMA that may still be waiting to issue
+  uint32_t a_off[PA], w_off[PW];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int r = (wave * PA + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+    a_off[i] = (uint32_t)(((size_t)min(m0 + r, M - 1) * lda + c * 8) * 2);
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     const int r = (wave * PW + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    w_src[i] = W + (size_t)min(n0 + r, N - 1) * ldw + c * 8;
+    w_off[i] = (uint32_t)(((size_t)min(n0 + r, N - 1) * ldw + c * 8) * 2);
   }
   const uint32_t lds_base = lds_addr(lds);
   auto stage = [&](int buf, int k0) {
     const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * PA * 1024);
     const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + A_BYTES + wave * PW * 1024);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(a_src[i] + k0, a_dst + i * 1024);
+    for (int i = 0; i < PA; ++i) glds16_so(A + k0, a_off[i], a_dst + i * 1024);
 #pragma unroll
-    for (int i = 0; i < PW; ++i) glds16(w_src[i] + k0, w_dst + i * 1024);
+    for (int i = 0; i < PW; ++i) glds16_so(W + k0, w_off[i], w_dst + i * 1024);
   };
 
   f32x4 acc[NT][MT];   // lane holds m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg

@@ -1312,6 +1312,19 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
+int rr_op_gemm_ln_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* x, const float* stats,
+                            const float* gamma, const float* beta, int M, int N, int Kd, float* out, void* hip_stream) {
+  if (!A || !W || !out || !x || !stats || !gamma || !beta) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm_ln(A, Kd, W, Kd, bias, x, N, stats, gamma, beta, out, N, M, N, Kd, EPI_BIAS_RESID_F32, g_op_dt,
+                                   (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+int rr_op_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                          float* out_f32, uint16_t* out_bf16, float* stats, void* hip_stream) {
+  if (!x || !gamma || !beta || !out_bf16 || !stats) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_layernorm_stats(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, stats, g_op_dt, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream) {
   if (!x || !gamma || !beta || (!out_f32 && !out_bf16)) return RR_ERR_BAD_ARG;

@@ -40,9 +40,11 @@ def test_production_gemm_equals_simple_gemm_through_the_forward(setup):
     finally:
         s["lib"].rr_set_gemm_variant(-1)
     assert torch.isfinite(a).all()
-    d = (a - b).abs().max().item()
-    print(f"full-size forward, ring kernel vs simple kernel: max |dlogit| {d:.2e}")
-    assert d <= 2e-3                                        # same rounding points; 16-bit ulp flips only
+    # same products, same fp32 accumulation order along K, same epilogue expressions: the two kernels agree to the bit
+    # (an intermittent 1e-3..8e-3 gap here was lost residual terms from compiler-packed f32 code, build.py)
+    assert torch.equal(a, b), f"max |dlogit| {(a - b).abs().max().item():.2e}"
+    c = _fwd(s)["logits"]
+    assert torch.equal(a, c)                                # and run to run
 
 
 def test_candidate_permutation_equivariance_and_rank(setup):

@@ -309,3 +309,41 @@ def test_gemm_production_kernel_equals_simple_kernel_at_bench_shape(lib):
             assert d.max().item() <= 2e-4
         else:   # 16-bit outputs: at most one ulp apart where the fp32 sums straddle a rounding boundary
             assert (d <= 2.0 ** -7 * (outs[1].abs() + 1e-3)).all() and (d > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12])
+def test_ln_residual_gemm_is_reproducible_and_matches_materialised_residual(lib, variant):
+    """out = A W^T + b + LN(x) with the residual recomputed from (x, mean, rstd, gamma, beta) inside the epilogue must be
+    bit-identical to the same GEMM fed the fp32 LayerNorm output, and identical run to run, at a size where every CU
+    holds several workgroups (this caught lost residual terms from compiler-packed f32 code; see build.py)."""
+    M, N, K = 200 * 512, 768, 3072
+    g = torch.Generator(device="cpu").manual_seed(11)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    x = torch.randn(M, N, generator=g).cuda()
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    bet = (0.05 * torch.randn(N, generator=g)).cuda()
+    ln32 = torch.empty(M, N, device="cuda")
+    ln16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    stats = torch.empty(M, 2, device="cuda")
+    assert lib.rr_op_layernorm_stats(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-12, M, N, ln32.data_ptr(),
+                                     ln16.data_ptr(), stats.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref_stats = torch.stack([x.mean(1), torch.rsqrt(x.var(1, unbiased=False) + 1e-12)], 1)
+    assert torch.allclose(stats, ref_stats, atol=1e-5, rtol=1e-5)
+    try:
+        assert lib.rr_set_gemm_variant(variant) == 0
+        plain = torch.empty(M, N, device="cuda")
+        assert lib.rr_op_gemm_resid_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), ln32.data_ptr(), M, N, K,
+                                        plain.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        for _ in range(4):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            assert lib.rr_op_gemm_ln_resid_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), x.data_ptr(), stats.data_ptr(),
+                                               gam.data_ptr(), bet.data_ptr(), M, N, K, out.data_ptr(), _stream()) == 0
+            torch.cuda.synchronize()
+            bad = (out != plain).nonzero()
+            assert len(bad) == 0, f"variant {variant}: {len(bad)} elements differ, first {bad[:4].tolist()}"
+    finally:
+        lib.rr_set_gemm_variant(-1)
