@@ -717,6 +717,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
       acc[Q][nt][mt] = mfma16<DT>(BF[nt], AF[mt], acc[Q][nt][mt]);
 #define RR_SBAR() __builtin_amdgcn_sched_barrier(0)
+  // wave priority falls with progress inside a barrier interval: of the two waves that share a SIMD the one that is
+  // BEHIND wins the MFMA pipe, so they advance together instead of the older wave racing ahead to idle at the barrier
+#define RR_PRIO(p) __builtin_amdgcn_s_setprio(p);
 
   // ---- prologue: half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3}); first fragments of tile 0
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
     read_a(sl + 0 * HALF, 1, AF1);                                                                         \
     read_b(sl + 1 * HALF, 1, B0K1);                                                                        \
     RR_SBAR();                                                                                             \
+    RR_PRIO(3)                                                                                             \
     RR_BLK(0, AF0, B0K0)                                                                                   \
     RR_SBAR();                                                                                             \
     RR_MARK(1)                                                                                             \
@@ -782,17 +786,20 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
     if (d1) RR_DMA(t + 1, 3)                                 /* A1 of the next tile (slot free since Y(t-1)) */ \
     RR_SBAR();                                                                                             \
     RR_MARK(2)                                                                                             \
+    RR_PRIO(2)                                                                                             \
     RR_BLK(0, AF1, B0K1)                                                                                   \
     RR_SBAR();                                                                                             \
     /* ---- p1: quadrant (A0, B1) */                                                                        \
     RR_MARK(3)                                                                                             \
     read_b(sl + 2 * HALF, 1, B1K1);                                                                        \
     RR_SBAR();                                                                                             \
+    RR_PRIO(1)                                                                                             \
     RR_BLK(1, AF0, B1K0)                                                                                   \
     RR_SBAR();                                                                                             \
     RR_MARK(4)                                                                                             \
     read_a(sl + 3 * HALF, 0, AF0);                                                                         \
     RR_SBAR();                                                                                             \
+    RR_PRIO(0)                                                                                             \
     RR_BLK(1, AF1, B1K1)                                                                                   \
     RR_SYNC(STEADY, 4, 4 * (t + 1) + 1, min(H - 1, 4 * (t + 1) + 3), 5)   /* X: A0(t+1), B0(t+1) landed */    \
     RR_ACC(0, 8)                                                                                           \
@@ -801,14 +808,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
     read_a(sl + 3 * HALF, 1, AF1);                                                                         \
     if (d2) RR_DMA(t + 2, 0)                                 /* slots A0, B0 (free since X) */               \
     RR_SBAR();                                                                                             \
+    RR_PRIO(3)                                                                                             \
     RR_BLK(3, AF0, B1K0)                                                                                   \
     RR_SBAR();                                                                                             \
     if (d2) RR_DMA(t + 2, 1)                                                                               \
     RR_SBAR();                                                                                             \
+    RR_PRIO(2)                                                                                             \
     RR_BLK(3, AF1, B1K1)                                                                                   \
     RR_SBAR();                                                                                             \
     RR_MARK(1)                                                                                             \
     /* ---- p3: quadrant (A1, B0) */                                                                        \
+    RR_PRIO(1)                                                                                             \
     RR_BLK(2, AF0, B0K0)                                                                                   \
     RR_SBAR();                                                                                             \
     if ((STEADY) || t + 1 < nk) {                                                                          \
@@ -817,6 +827,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
     }                                                                                                      \
     if (d2) RR_DMA(t + 2, 2)                                 /* slot B1 (free since X) */                    \
     RR_SBAR();                                                                                             \
+    RR_PRIO(0)                                                                                             \
     RR_BLK(2, AF1, B0K1)                                                                                   \
     RR_SYNC(STEADY, 6, 4 * (t + 1) + 3, min(H - 1, 4 * (t + 2) + 2), 2)   /* Y: B1(t+1), A1(t+1) landed */    \
     /* The next tile's first fragments are complete here (lgkmcnt(0) above).  Tell the compiler: otherwise it    \
