@@ -54,16 +54,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        const bf16_t* __restrict__ v, int kv_stride,
                                                        const float* __restrict__ key_bias, int heads,
                                                        int Tq, int Tk, bf16_t* __restrict__ out,
-                                                       int out_stride) {
+                                                       int out_stride, int groups) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
   float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64] raw additive key bias
   int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);   // [2] tile has a masked / out-of-range key
 
-  const int b = blockIdx.z, head = blockIdx.y;
+  // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
+  // read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
+  // into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
+  const int nqb = (Tq + 127) >> 7;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int grp = (local / nqb) * 8 + xcd, qblk = local - (local / nqb) * nqb;
+  if (grp >= groups) return;
+  const int b = grp / heads, head = grp - b * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int qrow = qblk * 128 + wave * 32 + (lane & 31);
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[query = lane&31][d = 16 i + 8 h + j]
   bf16x8 qf[4];
@@ -232,13 +239,14 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
-  if (B > 65535 || heads > 65535) return hipErrorInvalidValue;
-  dim3 grid((Tq + 127) / 128, heads, B), block(256);
+  const long groups = (long)B * heads, nqb = (Tq + 127) / 128, nblk = ((groups + 7) / 8) * 8 * nqb;
+  if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
+  dim3 grid((unsigned)nblk), block(256);
   if (dt == 0)
     hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
-                       key_bias, heads, Tq, Tk, out, out_stride);
+                       key_bias, heads, Tq, Tk, out, out_stride, (int)groups);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
-                       key_bias, heads, Tq, Tk, out, out_stride);
+                       key_bias, heads, Tq, Tk, out, out_stride, (int)groups);
   return hipGetLastError();
 }

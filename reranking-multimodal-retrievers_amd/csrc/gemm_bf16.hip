@@ -905,7 +905,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
       // stream the staged rows out, UNR 16-byte chunks per thread in flight at a time: the residual loads of a whole
       // batch are issued before the first add/store so that ~64-128 KiB per CU are outstanding (the 4-deep form ran
       // at ~8 B/clk/CU, below the ~12 B/clk/CU a pure streaming kernel reaches)
-      constexpr int UNR = 8;
+      constexpr int UNR = (EPI == EPI_BIAS_RESID_F32) ? 16 : 8;   // f32 residual pass: the whole 128-row pass in one batch
       // 512 threads cover 512/CPR whole rows per step, so a thread keeps ONE column chunk for the whole pass (its
       // gamma/beta are loaded once) and a wave keeps one row per step (its LayerNorm statistics are a scalar load).
       static_assert(512 % CPR == 0, "a wave must not straddle rows");
