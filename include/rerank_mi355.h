@@ -207,6 +207,27 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
 int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,
             float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream);
 
+/* ---- Host-side pair-input assembly (no GPU involved): WordPiece tokenisation of the (query, candidate) texts into the
+ * int64 [N, S] tensors rr_forward takes.  Replaces prepare_full_context_inputs (src/models/rerank/utils.py:129-167) and
+ * the BertTokenizer encode / decode / batch_encode_plus calls under it (transformers 4.38.2 slow tokenizer semantics).
+ * All pointers HOST.  A handle is immutable after creation and may be shared by threads. */
+typedef struct rr_tokenizer* rr_tokenizer_handle;
+/* vocab_tokens[i] = UTF-8 token with id i (the lines of vocab.txt); must contain [UNK] [CLS] [SEP] [PAD]. */
+int rr_tok_create(const char* const* vocab_tokens, int vocab_size, int do_lower_case, rr_tokenizer_handle* out);
+int rr_tok_destroy(rr_tokenizer_handle h);
+/* encode(text, add_special_tokens=False, max_length=max_tokens, truncation=True); max_tokens < 0 = no limit.
+ * Returns the number of ids written, or <0 (RR_ERR_BAD_SHAPE: capacity too small). */
+int rr_tok_encode(rr_tokenizer_handle h, const char* text, int max_tokens, int32_t* ids_out, int capacity);
+/* decode(ids) with clean_up_tokenization_spaces=True; returns the byte length (NUL-terminated), or <0. */
+int rr_tok_decode(rr_tokenizer_handle h, const int32_t* ids, int n, char* out, int capacity);
+/* The whole of prepare_full_context_inputs: queries[n_queries], contexts[n_queries * docs_per_query] (query-major);
+ * every text is truncated by an encode -> decode -> encode round trip (max_query_length / max_context_length tokens),
+ * pairs are encoded [CLS] q [SEP] c [SEP] with LONGEST_FIRST truncation to max_length and right padding (pad id,
+ * mask 0, type 0).  Outputs int64 [N, max_length], e.g. pinned buffers; n_threads <= 0 = hardware concurrency. */
+int rr_tok_prepare_pairs(rr_tokenizer_handle h, const char* const* queries, int n_queries, const char* const* contexts,
+                         int docs_per_query, int max_query_length, int max_context_length, int max_length, int n_threads,
+                         int64_t* input_ids, int64_t* attention_mask, int64_t* token_type_ids);
+
 /* Debug taps: copy an internal activation of the LAST rr_forward to HOST memory as float32.
  * names: "text_hidden" [n,S,H], "late_interaction" [n,T,D], "ce_hidden" [n,T,Hc]. Returns element
  * count written, or <0.  Synchronises the stream.  Test-only. */

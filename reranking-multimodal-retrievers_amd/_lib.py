@@ -76,6 +76,12 @@ _SIGS = {
     "rr_set_gemm_variant": (C.c_int, [C.c_int]),
     "rr_set_op_dtype": (C.c_int, [C.c_int]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "rr_tok_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rr_tok_destroy": (C.c_int, [C.c_void_p]),
+    "rr_tok_encode": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _P, C.c_int]),
+    "rr_tok_decode": (C.c_int, [C.c_void_p, _P, C.c_int, C.c_char_p, C.c_int]),
+    "rr_tok_prepare_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, _P, _P, _P]),
     "rr_op_layernorm_stats": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
     "rr_op_gemm_ln_resid_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rr_set_gemm_stamps": (C.c_int, [_P]),

@@ -13,8 +13,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librerank_mi355.so")
-SOURCES = ["rr_api.hip", "gemm_bf16.hip", "attention_bf16.hip", "elementwise.hip", "head.hip"]
-HEADERS = [os.path.join(CSRC, "rr_common.h"), os.path.join(os.path.dirname(HERE), "include", "rerank_mi355.h")]
+SOURCES = ["rr_api.hip", "gemm_bf16.hip", "attention_bf16.hip", "elementwise.hip", "head.hip", "pair_tokenizer.cpp"]
+HEADERS = [os.path.join(CSRC, "rr_common.h"), os.path.join(os.path.dirname(HERE), "include", "rerank_mi355.h"),
+           os.path.join(CSRC, "unicode_tables.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: no compiler-formed v_pk_*_f32.  With SLP on, the LayerNorm-residual epilogue of the 128x128 GEMM
 # (two workgroups per CU) came out as v_pk_add/mul/fma_f32 directly behind the s_waitcnt of the loads they read, and
@@ -42,9 +43,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         if force or _stale(obj, [src] + HEADERS):
-            jobs.append([HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
+            if s.endswith(".cpp"):       # host-only C++ (no device code)
+                jobs.append([HIPCC, "-O2", "-fPIC", "-std=c++17", "-Wall", "-pthread", "-c", src, "-o", obj])
+            else:
+                jobs.append([HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -56,9 +60,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs])
     return LIB
 
 

@@ -429,6 +429,8 @@ class FullContextRerankModel(torch.nn.Module):
       `image_feature_fn`– otherwise a callable pixel_values[Bq,3,224,224] -> (cls [Bq,Vh], patches [Bq,np,Vh]) that
                           wraps the reference-side `context_vision_encoder`
       `text_only`       – build without the vision weights (`text_only` module of the reference configs)
+      `native_tokenizer`– True: assemble the pair inputs with the library's multi-threaded C++ WordPiece tokenizer
+                          (rr_tok_prepare_pairs) built from `tokenizer`'s vocabulary instead of calling `tokenizer`
     """
 
     def __init__(self, config, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None):
@@ -442,6 +444,13 @@ class FullContextRerankModel(torch.nn.Module):
         self.max_decoder_source_length = _get(config, "max_decoder_source_length", 512)
         self.max_context_length = self.max_decoder_source_length - self.max_query_length - 4   # HEAD_TOKEN_LEEWAY
         self.query_tokenizer = _get(config, "tokenizer", None)
+        self.native_tokenizer = None
+        if _get(config, "native_tokenizer", False):
+            if self.query_tokenizer is None:
+                raise ValueError("native_tokenizer needs config.tokenizer (for its vocabulary)")
+            from .pair_inputs import NativePairTokenizer
+            self.native_tokenizer = NativePairTokenizer(self.query_tokenizer,
+                                                        do_lower_case=getattr(self.query_tokenizer, "do_lower_case", True))
         self.image_feature_fn = _get(config, "image_feature_fn", None)
         self.context_vision_encoder = _FrozenStub()
         if state_dict is not None:
@@ -486,10 +495,15 @@ class FullContextRerankModel(torch.nn.Module):
             assert len(labels) == expanded
         if self.query_tokenizer is None:
             raise RuntimeError("text call signature needs config.tokenizer (an HF-style BERT tokenizer)")
-        from .pair_inputs import prepare_full_context_inputs
-        enc = prepare_full_context_inputs(query_text_sequences, context_text_sequences, self.query_tokenizer,
-                                          self.max_query_length, self.max_context_length,
-                                          self.max_decoder_source_length, num_negative_examples + 1)
+        if self.native_tokenizer is not None:
+            enc = self.native_tokenizer.prepare_full_context_inputs(
+                list(query_text_sequences), list(context_text_sequences), self.max_query_length, self.max_context_length,
+                self.max_decoder_source_length, num_negative_examples + 1, pin_memory=True)
+        else:
+            from .pair_inputs import prepare_full_context_inputs
+            enc = prepare_full_context_inputs(query_text_sequences, context_text_sequences, self.query_tokenizer,
+                                              self.max_query_length, self.max_context_length,
+                                              self.max_decoder_source_length, num_negative_examples + 1)
         dev = self.engine.device
         cls = patches = None
         if not text_only:

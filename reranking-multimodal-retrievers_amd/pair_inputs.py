@@ -31,3 +31,72 @@ def prepare_full_context_inputs(query_text_sequences: List[str], context_text_se
         enc = tokenizer([q for q, _ in pairs], [c for _, c in pairs], **kw)
     return {"input_ids": enc["input_ids"].to(torch.int64), "attention_mask": enc["attention_mask"].to(torch.int64),
             "token_type_ids": enc["token_type_ids"].to(torch.int64)}
+
+
+class NativePairTokenizer:
+    """The same assembly in native code (csrc/pair_tokenizer.cpp behind `rr_tok_*`): multi-threaded WordPiece +
+    truncate-by-round-trip + pair encoding straight into pinned int64 host tensors, no Python per text.
+
+    `vocab` is the id-ordered token list (the lines of vocab.txt) or an HF tokenizer exposing `.vocab` / `get_vocab()`.
+    Semantics: transformers 4.38.2 slow `BertTokenizer` (what the reference pins), see the C++ file's header."""
+
+    def __init__(self, vocab, do_lower_case: bool = True, n_threads: int = 0):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.lib = L.load()
+        if not isinstance(vocab, (list, tuple)):
+            v = vocab.get_vocab() if hasattr(vocab, "get_vocab") else vocab.vocab
+            vocab = [t for t, _ in sorted(v.items(), key=lambda kv: kv[1])]
+        self.vocab = list(vocab)
+        arr = (C.c_char_p * len(self.vocab))(*[t.encode("utf-8") for t in self.vocab])
+        h = C.c_void_p()
+        L.check(self.lib.rr_tok_create(arr, len(self.vocab), int(do_lower_case), C.byref(h)), None, "rr_tok_create")
+        self.h, self.n_threads = h, int(n_threads)
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.rr_tok_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def encode(self, text: str, max_length: int = -1) -> List[int]:
+        C = self._C
+        raw = text.encode("utf-8", "replace")
+        cap = len(raw) + 8                                    # every id consumes at least one input byte
+        buf = (C.c_int32 * cap)()
+        n = self.lib.rr_tok_encode(self.h, raw, int(max_length), buf, cap)
+        if n < 0:
+            raise ValueError(f"rr_tok_encode failed ({n})")
+        return list(buf[:n])
+
+    def decode(self, ids) -> str:
+        C = self._C
+        ids = list(ids)
+        arr = (C.c_int32 * max(1, len(ids)))(*ids)
+        cap = 16 + sum(len(self.vocab[i].encode("utf-8")) + 1 for i in ids)
+        out = C.create_string_buffer(cap)
+        n = self.lib.rr_tok_decode(self.h, arr, len(ids), out, cap)
+        if n < 0:
+            raise ValueError(f"rr_tok_decode failed ({n})")
+        return out.raw[:n].decode("utf-8")
+
+    def prepare_full_context_inputs(self, query_text_sequences: List[str], context_text_sequences: List[str],
+                                    max_query_length: int, max_context_length: int, max_decoder_source_length: int,
+                                    docs_per_query: int, pin_memory: bool = False) -> Dict[str, torch.Tensor]:
+        C = self._C
+        nq = len(query_text_sequences)
+        N = nq * docs_per_query
+        assert N == len(context_text_sequences), "expanded batch size must be batch_size * docs_per_query"   # :527
+        q = (C.c_char_p * nq)(*[t.encode("utf-8", "replace") for t in query_text_sequences])
+        c = (C.c_char_p * N)(*[t.encode("utf-8", "replace") for t in context_text_sequences])
+        out = [torch.empty((N, max_decoder_source_length), dtype=torch.int64, pin_memory=pin_memory) for _ in range(3)]
+        rc = self.lib.rr_tok_prepare_pairs(self.h, q, nq, c, docs_per_query, max_query_length, max_context_length,
+                                           max_decoder_source_length, self.n_threads, out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr())
+        if rc != 0:
+            raise ValueError(f"rr_tok_prepare_pairs failed ({rc})")
+        return {"input_ids": out[0], "attention_mask": out[1], "token_type_ids": out[2]}
