@@ -202,6 +202,36 @@ def test_module_interface_returns_loss_and_logits():
     assert list(m.context_vision_encoder.named_parameters()) == []
 
 
+def test_text_call_signature_native_tokenizer_equals_hf_tokenizer(tmp_path):
+    """The reference call signature (texts in, .logits out) with the pair inputs assembled by the library's C++ tokenizer
+    and by the HF tokenizer object: same ids, hence bit-identical logits."""
+    import os
+    import rmr_amd
+    from transformers import BertTokenizer
+    g = load_golden("tiny")
+    cfg = g["cfg"]
+    words = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    words += ["what", "is", "the", "color", "of", "this", "bus", "red", "a", "big", "city", "street", "in", "london",
+              "double", "decker", ".", ",", "?", "##s", "##es", "buses", "are", "usually", "image", "query"]
+    f = os.path.join(tmp_path, "vocab.txt")
+    open(f, "w").write("\n".join(words) + "\n")
+    tok = BertTokenizer(f, do_lower_case=True)
+    assert len(words) <= cfg.vocab_size
+    w = O.make_weights(cfg, 0, False)
+    base = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn="BCE", pos_weight=None, max_query_length=6, max_decoder_source_length=32, text_only=True,
+                arch=arch_from_cfg(cfg, False), tokenizer=tok)
+    q = ["What is the color of this bus?", "a big city"]
+    c = ["London buses are usually red.", "Double decker buses, in London.", "", "this street is big", "the query image", "red"]
+    outs = []
+    for native in (False, True):
+        m = rmr_amd.FullContextRerankModel(dict(base, native_tokenizer=native), state_dict=w)
+        outs.append(m(query_text_sequences=q, query_pixel_values=None, context_text_sequences=c, num_negative_examples=2,
+                      labels=[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]))
+    assert outs[0].logits.shape == (6, 1)
+    assert torch.equal(outs[0].logits, outs[1].logits) and outs[0].loss.item() == outs[1].loss.item()
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_rerank_model_ids_signature(dtype):
     """RerankModel.forward (ids call signature): joint sequence, instruction masking, [query|image|context] reorder,
