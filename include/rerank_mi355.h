@@ -186,17 +186,30 @@ int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_
  * masking (id != 0 and (pos > first instruction_token_id position or pos < 2), :481-506; instruction_token_id < 0
  * = plain id != 0), cross-encoder token order [query | image | context] (:257-274), and the reference's
  * `loss_fn(logits, logits)` (:328: labels are ignored, the loss uses the logits as targets).  Image features are
- * mandatory (NotImplementedError for text_only, :184-185); `preflmr_scores` attention fusion is not supported. */
+ * mandatory (NotImplementedError for text_only, :184-185).  Attention fusion: rr_forward_joint_fusion. */
 int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
                      const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len,
                      int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out,
                      float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream);
 
+/* rr_forward_joint_fusion: rr_forward_joint with the PreFLMR attention fusion of RerankModel.forward
+ * (`preflmr_scores`, `fusion_multiplier`; rerank_model.py:276-319, attention_fusion.py:84-102; the executor passes the
+ * retriever's `scores_raw`, Reranker_base_executor.py:888-891).
+ *   preflmr_scores : DEVICE float32 [N, S, query_len + prefix_len + n_patches] — context token x query/image token.
+ * Rows 2 .. 2 + S - query_len of every pair (the context tokens that are in the joint sequence) give an additive
+ * attention bias over the cross-encoder tokens [query | image | context] in every cross-encoder layer: query rows get
+ * softmax-over-context-tokens, context rows softmax-over-query-tokens, the self blocks 0, all times fusion_multiplier. */
+int rr_forward_joint_fusion(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+                            const float* image_cls, const float* image_patches, const float* preflmr_scores,
+                            float fusion_multiplier, int Bq, int K, int S, int query_len, int64_t instruction_token_id,
+                            int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                            float* scores_out, int32_t* order_out, void* hip_stream);
+
 /* rr_forward_interaction: the Interaction rerankers, fed by the frozen retriever's late-interaction outputs
  * (Reranker_base_executor.py:877-885 builds the call).  All pointers DEVICE float32:
  *   query_li [Bq, Lq, li_dim], context_li [N, Lc, li_dim], query_mask [Bq, Lq] and context_mask [N, Lc] (0/1).
- * Outputs, labels, pair slice and head semantics are those of rr_forward.  `preflmr_scores` attention fusion is not
- * supported (no reference config enables it; MORES raises NotImplementedError for it too, mores_model.py:72-73). */
+ * Outputs, labels, pair slice and head semantics are those of rr_forward.  (No attention fusion here: the reference's
+ * interaction executor path never passes it and MORES raises NotImplementedError for it, mores_model.py:72-73.) */
 int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
                            const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
                            int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,

@@ -381,11 +381,28 @@ def instruction_query_mask(input_ids: Tensor, instruction_token_id: Optional[int
     return ((input_ids != 0) & ((idx > sep[:, None]) | (idx < 2))).to(torch.float32)
 
 
+def fusion_adjacency(preflmr_scores: Tensor, ql: int, P: int, S: int, fusion_multiplier: float) -> Tensor:
+    """PreFLMR attention fusion (rerank_model.py:276-319): the retriever's raw MaxSim score matrix
+    `preflmr_scores` [N, S, ql + P] (context token x query/image token), cut to the context tokens that are in the joint
+    sequence, becomes an additive attention bias over the cross-encoder tokens [query | image | context]:
+    query->context rows are softmax over the context tokens, context->query rows softmax over the query tokens, the two
+    self-attention blocks stay 0; all of it times `fusion_multiplier`."""
+    N = preflmr_scores.shape[0]
+    ts = preflmr_scores[:, 2: 2 - ql, :]                                                   # :277-279
+    assert ts.shape == (N, S - ql, ql + P)                                                  # :280-284
+    ul = torch.zeros(N, ql + P, ql + P)
+    br = torch.zeros(N, S - ql, S - ql)
+    ur = torch.softmax(ts.permute(0, 2, 1), dim=-1)                                         # :305
+    bl = torch.softmax(ts, dim=-1)                                                          # :306
+    return torch.cat([torch.cat([ul, ur], 2), torch.cat([bl, br], 2)], 1) * fusion_multiplier   # :309-315
+
+
 def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_ids: Tensor, query_attention_mask: Tensor,
                          context_input_ids: Tensor, context_attention_mask: Tensor, K: int, image_cls: Tensor,
                          image_patches: Tensor, instruction_token_id: Optional[int] = None, mm=None,
-                         want_taps: bool = False) -> OracleOutput:
-    """`RerankModel.forward` (rerank_model.py:171-331) without attention fusion (preflmr_scores=None)."""
+                         want_taps: bool = False, preflmr_scores: Optional[Tensor] = None,
+                         fusion_multiplier: float = 1.0) -> OracleOutput:
+    """`RerankModel.forward` (rerank_model.py:171-331), with the optional PreFLMR attention fusion."""
     Bq, ql = query_input_ids.shape
     N = Bq * K
     assert N == context_input_ids.shape[0]                                                  # :188
@@ -420,7 +437,8 @@ def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_id
     m = torch.cat([mask, torch.ones(N, P)], 1)                                              # :245-254
     xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)                            # :257-264
     m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)                                     # :267-274
-    l1, l2 = cross_encoder(cfg, w, xin, m, None, mm, taps)                                  # :321-325
+    adj = None if preflmr_scores is None else fusion_adjacency(preflmr_scores, ql, P, S, fusion_multiplier)
+    l1, l2 = cross_encoder(cfg, w, xin, m, adj, mm, taps)                                   # :321-325
     logits, _ = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, None)                 # :327
     # :328 `loss = self.loss_fn(logits, logits)` — the labels are ignored, the logits are their own targets
     if cfg.loss_fn == "BCE":

@@ -62,6 +62,8 @@ _SIGS = {
     "rr_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "rr_forward_joint": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                    _P, _P, _P, _P, _P, _P]),
+    "rr_forward_joint_fusion": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                          C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "rr_forward_interaction": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                          _P, _P, _P, _P, _P, _P]),
     "rr_head": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -47,14 +47,15 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int DT>
+template <int DT, bool DENSE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
                                                        int q_batch_div, int q_batch_off,
                                                        const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, int kv_stride,
                                                        const float* __restrict__ key_bias, int heads,
                                                        int Tq, int Tk, bf16_t* __restrict__ out,
-                                                       int out_stride, int groups) {
+                                                       int out_stride, int groups,
+                                                       const float* __restrict__ dense_bias, int dense_ld) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
@@ -139,8 +140,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
     // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
     // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
-    const bool masked = f_img[buf] != 0;             // wave-uniform: some key of this tile carries a bias
+    // DENSE: an additive bias per (query, key) on top of the per-key one (PreFLMR attention fusion,
+    // attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld], dense_ld a multiple of 64, zero padded
+    const bool masked = DENSE || f_img[buf] != 0;    // wave-uniform: some key of this tile carries a bias
     float mx;
+    if constexpr (DENSE) {
+      const float* dp = dense_bias + ((size_t)b * Tq + min(qrow, Tq - 1)) * dense_ld + t * KT + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 d0 = *(const float4*)(dp + 8 * g);
+        const float4 d1 = *(const float4*)(dp + 32 + 8 * g);
+        s0[4 * g + 0] += d0.x; s0[4 * g + 1] += d0.y; s0[4 * g + 2] += d0.z; s0[4 * g + 3] += d0.w;
+        s1[4 * g + 0] += d1.x; s1[4 * g + 1] += d1.y; s1[4 * g + 2] += d1.z; s1[4 * g + 3] += d1.w;
+      }
+    }
     if (masked) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -235,18 +248,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
-                               int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st) {
+                               int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st,
+                               const float* dense_bias, int dense_ld) {
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
   const long groups = (long)B * heads, nqb = (Tq + 127) / 128, nblk = ((groups + 7) / 8) * 8 * nqb;
   if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
   dim3 grid((unsigned)nblk), block(256);
-  if (dt == 0)
-    hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
-                       key_bias, heads, Tq, Tk, out, out_stride, (int)groups);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride,
-                       key_bias, heads, Tq, Tk, out, out_stride, (int)groups);
+  if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
+#define RR_ATTN(DT_, DENSE_)                                                                                        \
+  hipLaunchKernelGGL((attn_fwd_kernel<DT_, DENSE_>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, \
+                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld)
+  if (dt == 0) { if (dense_bias) RR_ATTN(0, true); else RR_ATTN(0, false); }
+  else { if (dense_bias) RR_ATTN(1, true); else RR_ATTN(1, false); }
+#undef RR_ATTN
   return hipGetLastError();
 }

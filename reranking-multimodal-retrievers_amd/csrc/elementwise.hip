@@ -265,6 +265,49 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restri
   ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, nullptr, 0);
 }
 
+// ---- PreFLMR attention fusion (rerank_model.py:276-319): additive attention bias over the cross-encoder tokens
+// [query | image | context] from the retriever's raw score matrix scores[pair][S][Tq] (context token x query/image token):
+//   adj[i < Tq][Tq + kc] = mult * softmax over kc of ts[kc][i]      (query row attends context)
+//   adj[Tq + kc][j < Tq] = mult * softmax over j  of ts[kc][j]      (context row attends query)
+//   0 elsewhere (the two self-attention blocks, and the padding columns up to ld), with ts[kc][*] = scores[2 + kc][*],
+//   kc < Tc = S - ql.  One workgroup per pair.
+__global__ __launch_bounds__(256) void fusion_adj_kernel(const float* __restrict__ scores, int S, int Tq, int Tc, float mult,
+                                                         int pair0, float* __restrict__ adj, int ld) {
+  extern __shared__ float colstat[];                 // [Tq] max, [Tq] 1/sum
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ts = scores + ((size_t)(pair0 + b) * S + 2) * Tq;
+  float* A = adj + (size_t)b * (Tq + Tc) * ld;
+  for (int i = tid; i < Tq; i += 256) {              // column statistics (softmax over the context tokens)
+    float mx = -INFINITY;
+    for (int kc = 0; kc < Tc; ++kc) mx = fmaxf(mx, ts[(size_t)kc * Tq + i]);
+    float sum = 0.f;
+    for (int kc = 0; kc < Tc; ++kc) sum += expf(ts[(size_t)kc * Tq + i] - mx);
+    colstat[i] = mx;
+    colstat[Tq + i] = 1.f / sum;
+  }
+  __syncthreads();
+  for (int i = wave; i < Tq; i += 4) {               // upper rows: [0 | softmax over context]
+    float* row = A + (size_t)i * ld;
+    const float mx = colstat[i], inv = colstat[Tq + i];
+    for (int j = lane; j < ld; j += 64) {
+      const int kc = j - Tq;
+      row[j] = (kc >= 0 && kc < Tc) ? mult * (expf(ts[(size_t)kc * Tq + i] - mx) * inv) : 0.f;
+    }
+  }
+  for (int kc = wave; kc < Tc; kc += 4) {            // lower rows: [softmax over query/image tokens | 0]
+    const float* r = ts + (size_t)kc * Tq;
+    float mx = -INFINITY;
+    for (int j = lane; j < Tq; j += 64) mx = fmaxf(mx, r[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tq; j += 64) sum += expf(r[j] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float* row = A + (size_t)(Tq + kc) * ld;
+    for (int j = lane; j < ld; j += 64) row[j] = j < Tq ? mult * (expf(r[j] - mx) * inv) : 0.f;
+  }
+}
+
 // ---- interaction rerankers: key bias over the concatenated [query tokens | context tokens] sequence from the
 // retriever's 0/1 masks (interaction_rerank_model.py:153); also the two separate biases MORES needs.
 __global__ void interaction_bias_kernel(const float* __restrict__ qmask, const float* __restrict__ cmask, int n, int Lq,
@@ -398,6 +441,13 @@ hipError_t rr_launch_vit_embed_ln(const float* patches, const float* cls_emb, co
   if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   hipLaunchKernelGGL(vit_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, patches, cls_emb, pos, gamma, beta, eps,
                      rows, T, cols, o32);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_fusion_adj(const float* scores, int S, int Tq, int Tc, float mult, int pair0, int n, float* adj, int ld,
+                                hipStream_t st) {
+  if (n <= 0 || Tq <= 0 || Tc <= 0 || 2 + Tc > S || ld < Tq + Tc || (ld & 63) || Tq > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fusion_adj_kernel, dim3(n), dim3(256), 2 * Tq * sizeof(float), st, scores, S, Tq, Tc, mult, pair0, adj, ld);
   return hipGetLastError();
 }
 

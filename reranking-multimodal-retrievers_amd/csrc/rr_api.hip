@@ -124,6 +124,9 @@ struct rr_model {
   float* b_cemap = nullptr;
   float *ce_pos = nullptr, *ce_type = nullptr, *ce_emb_g = nullptr, *ce_emb_b = nullptr;
   float *cls1_w = nullptr, *cls1_b = nullptr, *cls2_w = nullptr, *cls2_b = nullptr;
+  // PreFLMR attention-fusion bias (grow-only, only when rr_forward_joint_fusion is used)
+  float* adj = nullptr;
+  size_t adj_cap = 0;
   // CLIP ViT (optional)
   std::vector<LayerW> vit_layers;
   bf16_t* vit_wpatch = nullptr;                             // [Vh, Kp] patch convolution, zero-padded to Kp
@@ -560,12 +563,13 @@ struct ResidSrc {
 // One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).  In: w.h16 (bf16 LayerNorm output of the
 // previous block) and `rs`; out: w.h16, `rs` updated to this layer's LN2 (and w.h32 when `want_h32`).
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
-              const float* key_bias, Work& w, ResidSrc& rs, bool want_h32) {
+              const float* key_bias, Work& w, ResidSrc& rs, bool want_h32, const float* dense_bias = nullptr,
+              int dense_ld = 0) {
   const int rows = batch * Tseq;
   RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
          rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
-                             Tseq, w.ctx, Hd, m->dt, st));
+                             Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld));
   if (!g_ln_lite) {   // reference dataflow for A/B runs: every LayerNorm writes the fp32 stream, residuals read it back
     RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
@@ -619,7 +623,7 @@ int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K,
 
 // CrossEncoder over AttentionFusionBertModel (utils.py:85-108, attention_fusion.py:61-160): Linear(D -> Hc) ->
 // embeddings(inputs_embeds) -> Lc layers.  Input: w.li16 [n*T, D], w.ce_bias [n, T]; output: w.h32 [n*T, Hc].
-int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T) {
+int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const float* adj = nullptr, int adj_ld = 0) {
   const rr_config& c = m->cfg;
   const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate, RT = n * T;
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
@@ -629,7 +633,8 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T) {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
     for (int l = 0; l < c.ce_layers; ++l)
       RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs,
-                       l == c.ce_layers - 1));              // the CLS heads read the fp32 rows of the last layer
+                       l == c.ce_layers - 1,                // the CLS heads read the fp32 rows of the last layer
+                       adj, adj_ld));                       // attention fusion: the same bias in every layer
   }
   m->tap_ce = w.h32;
   m->tap_ce_elems = (size_t)RT * Hc;
@@ -751,6 +756,7 @@ int rr_destroy(rr_handle h) {
   for (void* p : h->dev_allocs) (void)hipFree(p);
   if (h->ws) (void)hipFree(h->ws);
   if (h->tap_text) (void)hipFree(h->tap_text);
+  if (h->adj) (void)hipFree(h->adj);
   for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   delete h;
   return RR_OK;
@@ -948,7 +954,8 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
                         const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int Bq, int K,
                         int S, const float* labels, int pair_begin, int pair_end, float* logits_out,
                         float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream,
-                        int joint, int q_len, long long instruction_token) {
+                        int joint, int q_len, long long instruction_token, const float* preflmr_scores = nullptr,
+                        float fusion_multiplier = 1.0f) {
   if (!h) return RR_ERR_BAD_ARG;
   rr_model* m = h;
   const rr_config& c = m->cfg;
@@ -1098,7 +1105,22 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)RT * D;
 
-  RR_TRY(run_cross_encoder(m, st, w, n, T));
+  const float* adj = nullptr;
+  int adj_ld = 0;
+  if (preflmr_scores) {   // rerank_model.py:276-319: scores [N, S, q_len + P] -> additive bias [n, T, ld]
+    if (!joint) return fail(m, RR_ERR_BAD_ARG, "attention fusion belongs to the joint (RerankModel) forward");
+    adj_ld = (T + 63) / 64 * 64;
+    const size_t need_adj = (size_t)n * T * adj_ld * sizeof(float);
+    if (need_adj > m->adj_cap) {
+      if (m->adj) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->adj)); m->adj = nullptr; m->adj_cap = 0; }
+      RR_HIP(m, hipMalloc((void**)&m->adj, need_adj));
+      m->adj_cap = need_adj;
+    }
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * (double)S * (q_len + P) + (double)need_adj,
+           rr_launch_fusion_adj(preflmr_scores, S, q_len + P, S - q_len, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st));
+    adj = m->adj;
+  }
+  RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld));
   return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
                    loss_out, scores_out, order_out, joint != 0);
 }
@@ -1119,6 +1141,17 @@ int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t*
   return forward_full(h, joint_input_ids, joint_attention_mask, nullptr, image_cls, image_patches, Bq, K, S, nullptr,
                       pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, 1,
                       query_len, (long long)instruction_token_id);
+}
+
+int rr_forward_joint_fusion(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+                            const float* image_cls, const float* image_patches, const float* preflmr_scores,
+                            float fusion_multiplier, int Bq, int K, int S, int query_len, int64_t instruction_token_id,
+                            int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                            float* scores_out, int32_t* order_out, void* hip_stream) {
+  if (h && !preflmr_scores) return fail(h, RR_ERR_BAD_ARG, "rr_forward_joint_fusion: preflmr_scores is null (use rr_forward_joint)");
+  return forward_full(h, joint_input_ids, joint_attention_mask, nullptr, image_cls, image_patches, Bq, K, S, nullptr,
+                      pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, 1,
+                      query_len, (long long)instruction_token_id, preflmr_scores, fusion_multiplier);
 }
 
 /* InteractionRerankModel.forward (interaction_rerank_model.py:110-166) from the retriever's late-interaction

@@ -320,8 +320,10 @@ class RerankEngine:
     def forward_joint(self, joint_input_ids: torch.Tensor, joint_attention_mask: torch.Tensor, Bq: int, K: int,
                       query_len: int, image_cls: torch.Tensor, image_patches: torch.Tensor,
                       instruction_token_id: Optional[int] = None, want_scores: bool = False, want_order: bool = False,
-                      pair_range: Optional[Sequence[int]] = None, want_loss: bool = True):
-        """RerankModel.forward semantics on the assembled joint sequence (see rr_forward_joint)."""
+                      pair_range: Optional[Sequence[int]] = None, want_loss: bool = True,
+                      preflmr_scores: Optional[torch.Tensor] = None, fusion_multiplier: float = 1.0):
+        """RerankModel.forward semantics on the assembled joint sequence (see rr_forward_joint); `preflmr_scores`
+        [N, S, query_len + image tokens] switches the PreFLMR attention fusion on (rr_forward_joint_fusion)."""
         dev = self.device
         N, S = joint_input_ids.shape
         assert N == Bq * K
@@ -336,11 +338,22 @@ class RerankEngine:
         scores = torch.empty(N, **f32) if (full and want_scores) else None
         order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if (full and want_order) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
-        L.check(self.lib.rr_forward_joint(self.h, L.ptr(joint_input_ids.contiguous()),
-                                          L.ptr(joint_attention_mask.contiguous()), L.ptr(cls), L.ptr(patches), Bq, K, S,
-                                          int(query_len), -1 if instruction_token_id is None else int(instruction_token_id),
-                                          pb, pe, L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
-                                          L.ptr(order), stream), self.h, "rr_forward_joint")
+        instr = -1 if instruction_token_id is None else int(instruction_token_id)
+        if preflmr_scores is not None:
+            P = self.arch["prefix_len"] + self.arch["n_patches"]
+            ps = preflmr_scores.to(**f32).contiguous()
+            if tuple(ps.shape) != (N, S, int(query_len) + P):                                   # rerank_model.py:280-284
+                raise AssertionError(f"preflmr_scores must be [{N}, {S}, {int(query_len) + P}], got {tuple(ps.shape)}")
+            L.check(self.lib.rr_forward_joint_fusion(self.h, L.ptr(joint_input_ids.contiguous()),
+                                                     L.ptr(joint_attention_mask.contiguous()), L.ptr(cls), L.ptr(patches),
+                                                     L.ptr(ps), float(fusion_multiplier), Bq, K, S, int(query_len), instr, pb,
+                                                     pe, L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
+                                                     L.ptr(order), stream), self.h, "rr_forward_joint_fusion")
+        else:
+            L.check(self.lib.rr_forward_joint(self.h, L.ptr(joint_input_ids.contiguous()),
+                                              L.ptr(joint_attention_mask.contiguous()), L.ptr(cls), L.ptr(patches), Bq, K, S,
+                                              int(query_len), instr, pb, pe, L.ptr(logits), L.ptr(logits2), L.ptr(loss),
+                                              L.ptr(scores), L.ptr(order), stream), self.h, "rr_forward_joint")
         return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
 
     def forward_interaction(self, query_li: torch.Tensor, context_li: torch.Tensor, query_mask: torch.Tensor,
@@ -584,8 +597,6 @@ class RerankModel(torch.nn.Module):
                 image_features=None, **kw) -> RerankOutput:
         if query_pixel_values is None and image_features is None:
             raise NotImplementedError("text_only is not implemented for this model")        # rerank_model.py:184-185
-        if preflmr_scores is not None:
-            raise NotImplementedError("preflmr_scores attention fusion is not implemented on this path")
         K = num_negative_examples + 1
         Bq = query_input_ids.size(0)
         N = Bq * K
@@ -610,7 +621,8 @@ class RerankModel(torch.nn.Module):
             else:
                 raise NotImplementedError("query_pixel_values given but neither config.vision_encoder nor "
                                           "config.image_feature_fn (CLIP ViT) is set")
-        r = self.engine.forward_joint(joint_ids, joint_am, Bq, K, ql, cls, patches, self.instruction_token_id, **kw)
+        r = self.engine.forward_joint(joint_ids, joint_am, Bq, K, ql, cls, patches, self.instruction_token_id,
+                                      preflmr_scores=preflmr_scores, fusion_multiplier=float(fusion_multiplier), **kw)
         out = RerankOutput(loss=r["loss"], logits=r["logits"].view(N, 1))
         for k in ("scores", "order", "logits2"):
             if r.get(k) is not None:

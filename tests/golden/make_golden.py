@@ -162,8 +162,9 @@ class HFInteraction:
         return loss, logits
 
 
-def run_rerankmodel_case(outdir, name="rm_tiny"):
-    """RerankModel.forward (ids signature) with instruction masking and the [query|image|context] reorder."""
+def run_rerankmodel_case(outdir, name="rm_tiny", fusion=False):
+    """RerankModel.forward (ids signature) with instruction masking and the [query|image|context] reorder; `fusion`
+    adds the PreFLMR attention-fusion bias (rerank_model.py:276-319) from seeded retriever scores."""
     kw = dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_pos=64, ce_hidden=128, ce_heads=2,
               ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64, vision_hidden=128, prefix_len=4, n_patches=9,
               cross_attn_len=32, pos_weight=2.0)
@@ -200,18 +201,31 @@ def run_rerankmodel_case(outdir, name="rm_tiny"):
         m = torch.cat([mask, torch.ones(N, xin.shape[1] - S)], 1)
         xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)
         m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)
-        cls = hf.ce(inputs_embeds=xin, attention_mask=m).last_hidden_state[:, 0]
+        scores, mult = None, 1.0
+        if fusion:
+            gs = torch.Generator().manual_seed(99)
+            scores = 3.0 * torch.randn(N, S, ql + xin.shape[1] - S, generator=gs)      # retriever scores_raw stand-in
+            mult = 20.0
+            adj = O.fusion_adjacency(scores, ql, xin.shape[1] - S, S, mult)
+            ext = (1.0 - m)[:, None, None, :] * torch.finfo(torch.float32).min + adj[:, None]
+            emb = hf.ce.embeddings(inputs_embeds=xin)
+            cls = hf.ce.encoder(emb, attention_mask=ext).last_hidden_state[:, 0]       # stock BertEncoder, additive 4-D mask
+        else:
+            cls = hf.ce(inputs_embeds=xin, attention_mask=m).last_hidden_state[:, 0]
         l12 = torch.cat((hf.lin(cls, "reranker.classifier1"), hf.lin(cls, "reranker.classifier2")), 1)
         loss_hf = torch.nn.functional.cross_entropy(l12, l12, weight=torch.tensor([1.0, cfg.pos_weight]))
         logits_hf = l12[:, 1:2]
-        out = O.rerank_model_forward(cfg, w, q_ids, q_am, c_ids, c_am, K, img[0], img[1], instr)
+        out = O.rerank_model_forward(cfg, w, q_ids, q_am, c_ids, c_am, K, img[0], img[1], instr, preflmr_scores=scores,
+                                     fusion_multiplier=mult)
     d_logit, d_loss = (out.logits - logits_hf).abs().max().item(), (out.loss - loss_hf).abs().item()
     print(f"[{name}] oracle-vs-HF: logits {d_logit:.3e} loss {d_loss:.3e}")
     np.savez_compressed(os.path.join(outdir, f"{name}.npz"), cfg_json=np.array(repr(kw)), Bq=Bq, K=K, S=S, ql=ql,
                         instruction_token_id=instr, query_input_ids=q_ids.numpy(), query_attention_mask=q_am.numpy(),
                         context_input_ids=c_ids.numpy(), context_attention_mask=c_am.numpy(),
                         image_cls=img[0].numpy(), image_patches=img[1].numpy(), logits=logits_hf.numpy(),
-                        loss=np.array(loss_hf.item(), dtype=np.float32), oracle_vs_hf=np.array([d_logit, d_loss]))
+                        loss=np.array(loss_hf.item(), dtype=np.float32), oracle_vs_hf=np.array([d_logit, d_loss]),
+                        fusion=np.array(int(fusion)), fusion_multiplier=np.array(mult, dtype=np.float32),
+                        preflmr_scores=(scores.numpy() if fusion else np.zeros(0, dtype=np.float32)))
 
 
 VIT_CASES = {
@@ -347,12 +361,14 @@ def run_case(name, outdir):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny"] + list(VIT_CASES)))
+    ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny", "rm_fuse_tiny"] + list(VIT_CASES)))
     a = ap.parse_args()
     torch.set_num_threads(8)
     for nm in a.which.split(","):
         if nm == "rm_tiny":
             run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)))
+        elif nm == "rm_fuse_tiny":
+            run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)), name="rm_fuse_tiny", fusion=True)
         elif nm in INTERACTION_CASES:
             run_interaction_case(nm, os.path.dirname(os.path.abspath(__file__)))
         elif nm in VIT_CASES:

@@ -260,9 +260,63 @@ def test_rerank_model_ids_signature(dtype):
     assert out.logits.shape == (int(z["Bq"]) * K, 1)
     with pytest.raises(NotImplementedError):
         m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"), K - 1)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                      # preflmr_scores must be [N, S, ql + image tokens]
         m(t("query_input_ids"), t("query_attention_mask"), None, t("context_input_ids"), t("context_attention_mask"), K - 1,
           image_features=(t("image_cls"), t("image_patches")), preflmr_scores=torch.zeros(1))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_rerank_model_attention_fusion(dtype):
+    """RerankModel.forward with `preflmr_scores` (PreFLMR attention fusion, rerank_model.py:276-319): the additive
+    [T, T] bias built on the device and applied inside the attention kernel, against the stock-HF golden (BertEncoder
+    fed the additive 4-D mask) and the same-rounding oracle; the bias moves these logits by 7e-3, 30x the tolerance."""
+    import ast, os
+    import numpy as np
+    import rmr_amd
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "rm_fuse_tiny.npz"), allow_pickle=False)
+    z0 = np.load(os.path.join(GOLDEN, "rm_tiny.npz"), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg_json"])))
+    cfg.loss_fn = "2H_BCE"
+    w = O.make_weights(cfg, seed=0, vision=True)
+    conf = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn="2H_BCE", pos_weight=cfg.pos_weight, instruction_token_id=int(z["instruction_token_id"]),
+                arch=arch_from_cfg(cfg, True, dtype))
+    m = rmr_amd.RerankModel(conf, state_dict=w)
+    t = lambda k: torch.from_numpy(z[k])
+    K, mult = int(z["K"]), float(z["fusion_multiplier"])
+    args = (t("query_input_ids").cuda(), t("query_attention_mask").cuda(), None, t("context_input_ids").cuda(),
+            t("context_attention_mask").cuda(), K - 1)
+    out = m(*args, preflmr_scores=t("preflmr_scores").cuda(), fusion_multiplier=mult,
+            image_features=(t("image_cls").cuda(), t("image_patches").cuda()))
+    torch.cuda.synchronize()
+    gold = torch.from_numpy(z["logits"])
+    d = (out.logits.cpu() - gold).abs().max().item()
+    with torch.no_grad(), O.device_rounding(torch.bfloat16 if dtype == "bf16" else torch.float16) as mm:
+        emu = O.rerank_model_forward(cfg, w, t("query_input_ids"), t("query_attention_mask"), t("context_input_ids"),
+                                     t("context_attention_mask"), K, t("image_cls"), t("image_patches"),
+                                     int(z["instruction_token_id"]), mm=mm, preflmr_scores=t("preflmr_scores"),
+                                     fusion_multiplier=mult)
+    demu = (out.logits.cpu() - emu.logits).abs().max().item()
+    effect = (gold - torch.from_numpy(z0["logits"])).abs().max().item()
+    print(f"[rm_fuse_tiny/{dtype}] |dlogit| vs fp32 golden {d:.2e}, vs same-rounding oracle {demu:.2e}; fusion moves the logits by {effect:.2e}")
+    assert effect > 5e-3
+    assert d < (2.5e-4 if dtype == "fp16" else 1e-3) and demu < 2.5e-4
+    assert abs(out.loss.item() - float(z["loss"])) < 2e-3
+    # pair slices compose (the bias rows follow the slice)
+    Bq = int(z["Bq"])
+    N = Bq * K
+    eng = m.engine
+    ql, S = z["query_input_ids"].shape[1], z["context_input_ids"].shape[1]
+    q_ids = t("query_input_ids").cuda().repeat_interleave(K, 0)
+    q_am = t("query_attention_mask").cuda().repeat_interleave(K, 0)
+    j_ids = torch.cat([q_ids, t("context_input_ids").cuda()[:, 2:2 - ql]], 1).contiguous()
+    j_am = torch.cat([q_am, t("context_attention_mask").cuda()[:, 2:2 - ql]], 1).contiguous()
+    kw = dict(preflmr_scores=t("preflmr_scores").cuda(), fusion_multiplier=mult, want_loss=False)
+    parts = [eng.forward_joint(j_ids, j_am, Bq, K, ql, t("image_cls").cuda(), t("image_patches").cuda(),
+                               int(z["instruction_token_id"]), pair_range=r, **kw)["logits"][r[0]:r[1]] for r in ((0, 2), (2, N))]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), out.logits.view(-1))
 
 
 def test_batched_rerank_loop_on_device_orders():

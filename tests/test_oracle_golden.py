@@ -134,3 +134,27 @@ def test_vision_tower_oracle_matches_golden(name):
     np.testing.assert_allclose(c.numpy(), z["image_cls"], atol=5e-5, rtol=0)
     np.testing.assert_allclose(p.numpy(), z["image_patches"], atol=5e-5, rtol=0)
     assert z["oracle_vs_hf"].max() < 5e-5
+
+
+def test_attention_fusion_oracle_matches_golden():
+    """RerankModel with the PreFLMR attention-fusion bias: restatement vs stock HF BertEncoder on the additive mask."""
+    import ast, os
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "rm_fuse_tiny.npz"), allow_pickle=False)
+    cfg = O.OracleConfig(**ast.literal_eval(str(z["cfg_json"])))
+    cfg.loss_fn = "2H_BCE"
+    w = O.make_weights(cfg, seed=0, vision=True)
+    t = lambda k: torch.from_numpy(z[k])
+    with torch.no_grad():
+        out = O.rerank_model_forward(cfg, w, t("query_input_ids"), t("query_attention_mask"), t("context_input_ids"),
+                                     t("context_attention_mask"), int(z["K"]), t("image_cls"), t("image_patches"),
+                                     int(z["instruction_token_id"]), preflmr_scores=t("preflmr_scores"),
+                                     fusion_multiplier=float(z["fusion_multiplier"]))
+        adj = O.fusion_adjacency(t("preflmr_scores"), 8, 13, 64, 1.0)
+    np.testing.assert_allclose(out.logits.numpy(), z["logits"], atol=2e-6, rtol=0)
+    assert z["oracle_vs_hf"][0] < 1e-6 and int(z["fusion"]) == 1
+    # structure of the bias: zero self blocks, rows of the two cross blocks are probability distributions
+    Tq = 8 + 13
+    assert adj[:, :Tq, :Tq].abs().max() == 0 and adj[:, Tq:, Tq:].abs().max() == 0
+    assert torch.allclose(adj[:, :Tq, Tq:].sum(-1), torch.ones(adj.shape[0], Tq), atol=1e-5)
+    assert torch.allclose(adj[:, Tq:, :Tq].sum(-1), torch.ones(adj.shape[0], adj.shape[1] - Tq), atol=1e-5)
