@@ -286,6 +286,7 @@ int rr_set_gemm_variant(int variant);
 int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
+int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */
 int rr_set_gemm_stagger(int unit);   /* start skew of the first dispatch wave, in s_sleep(127) units; 0 = off */
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream);

@@ -78,6 +78,7 @@ _SIGS = {
     "rr_set_gemm_variant": (C.c_int, [C.c_int]),
     "rr_set_op_dtype": (C.c_int, [C.c_int]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "rr_set_attn_stamps": (C.c_int, [_P]),
     "rr_tok_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rr_tok_destroy": (C.c_int, [C.c_void_p]),
     "rr_tok_encode": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _P, C.c_int]),

@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int DT, bool DENSE>
+template <int DT, bool DENSE, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
                                                        int q_batch_div, int q_batch_off,
                                                        const bf16_t* __restrict__ k,
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        const float* __restrict__ key_bias, int heads,
                                                        int Tq, int Tk, bf16_t* __restrict__ out,
                                                        int out_stride, int groups,
-                                                       const float* __restrict__ dense_bias, int dense_ld) {
+                                                       const float* __restrict__ dense_bias, int dense_ld,
+                                                       unsigned long long* __restrict__ stamps) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
@@ -116,12 +117,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;   // running max (log2 domain) and this lane's partial row sum
 
+  // diagnostic build: s_memtime marks per KV tile (read after the tile's barrier), summed per wave
+  unsigned long long dg[5] = {0, 0, 0, 0, 0}, tmk[6];
+#define RR_MARK(k) { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
   const int nt = (Tk + KT - 1) / KT;
   RR_LOAD_TILE(0)
   RR_WRITE_TILE(0)
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
+    RR_MARK(0)
     if (t + 1 < nt) RR_LOAD_TILE(t + 1)
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       s0 = mfma32<DT>(k0, qf[i], s0);
       s1 = mfma32<DT>(k1, qf[i], s1);
     }
+    RR_MARK(1)
     // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
     // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
     // DENSE: an additive bias per (query, key) on top of the per-key one (PreFLMR attention fusion,
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
+    RR_MARK(2)
     // ---- O^T += V^T P^T.  P fragment for k-step s of key block kb = regs 8s..8s+7 (k order:
     // element j <-> key 16 s + 8 (j>>2) + 4 h + (j&3)); V fragment gathers the same keys.
 #pragma unroll
@@ -225,9 +232,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         o1 = mfma32<DT>(v1, pf, o1);
       }
     }
+    RR_MARK(3)
     if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
+    RR_MARK(4)
     __syncthreads();
+    RR_MARK(5)
+    if constexpr (DIAG) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k_ = 0; k_ < 5; ++k_) dg[k_] += tmk[k_ + 1] - tmk[k_];
+    }
   }
+  if constexpr (DIAG) {
+    if (stamps && lane == 0)
+      for (int k_ = 0; k_ < 5; ++k_) stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = dg[k_];
+    if (stamps && tid == 0) stamps[((size_t)blockIdx.x * 4) * 8 + 7] = (unsigned long long)nt;
+  }
+#undef RR_MARK
 
   // ---- epilogue: O = O^T / l ; lane writes 4 consecutive d per register group
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -246,6 +267,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
 }  // namespace
 
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
+  g_attn_stamps = (unsigned long long*)device_buf;
+  return 0;
+}
+
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
                                int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st,
@@ -259,7 +286,12 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
 #define RR_ATTN(DT_, DENSE_)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<DT_, DENSE_>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, \
-                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld)
+                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, nullptr)
+  if (g_attn_stamps && dt == 0 && !dense_bias) {   // diagnostic timeline (tools/attn_timeline.py)
+    hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v,
+                       kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, g_attn_stamps);
+    return hipGetLastError();
+  }
   if (dt == 0) { if (dense_bias) RR_ATTN(0, true); else RR_ATTN(0, false); }
   else { if (dense_bias) RR_ATTN(1, true); else RR_ATTN(1, false); }
 #undef RR_ATTN
