@@ -2,7 +2,7 @@
 stock-HF assembly (fp32), (b) the CPU oracle run with the device's bf16 rounding points.
 
 Tolerances (DESIGN.md "Numerics"): bf16 operand rounding alone moves bert-base logits by ~2e-3 against an
-fp32 forward (the reference's own bf16-mixed forward moves by 1.3e-3..6e-3; tools/precision_study.py), so
+fp32 forward (the reference's own bf16-mixed forward moves by 1.3e-3..6e-3; tests/tools/precision_study.py), so
   * vs the oracle WITH the same rounding points: |dlogit| <= 1e-3   (north_star: "within 1e-3 bf16")
   * vs the fp32 goldens:                          |dlogit| <= 8e-3   (bounded by bf16 itself, not by the kernels)
 """
