@@ -981,10 +981,413 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   stamp(stamps, 3);
 }
 
+// Variant HP ("persistent ring"): gemm_kernel_h with one workgroup per CU walking several output tiles.  Before a tile's
+// epilogue starts, the first five half-tiles of the NEXT tile are already requested into ring slots 0-4 (free since the
+// main loop's last barrier); the epilogue stages through the other half of the LDS ([80 KiB, 160 KiB), two 128-row passes
+// for 16-bit output, four 64-row passes for fp32), so the 5-6k-cycle cold prologue of every tile but the first hides
+// behind the previous tile's epilogue.  Same main loop, same arithmetic, same results as gemm_kernel_h.
+template <int EPI, int DT>
+__global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__ A, int lda,
+                                                     const bf16_t* __restrict__ W, int ldw,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ resid, int ldr,
+                                                     void* __restrict__ Cv, int ldc, int M, int N, int Kd,
+                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
+                                                     int stagger_unit) {
+  constexpr bool DIAG = false;
+  stamp(stamps, 0);
+  constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  // persistent XCD-aware walk: workgroup (xcd = bid & 7, j = bid >> 3) takes the tiles chunk0 + j + i * (grid / 8) of its
+  // XCD's contiguous chunk of the tile list, i = 0, 1, ...
+  const int bid = blockIdx.x, gstep = (int)(gridDim.x >> 3);
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  int li = bid >> 3;
+  if (li >= chunk_n) return;
+  int m0, n0;
+  { const int tile = chunk0 + li, tm = tile / tiles_n; m0 = tm * BM; n0 = (tile - tm * tiles_n) * BN; }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- DMA sources: half-tile j in {0:A0, 1:B0, 2:B1, 3:A1}; this wave moves pieces 2*wave, 2*wave+1 (8 rows each).
+  // 32-bit byte offsets from the (scalar) A / W base: operands are < 4 GiB.
+  uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
+#define RR_SETUP_SRC(m0_, n0_)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);          /* row inside the half-tile */             \
+    const int c = (lane & 7) ^ ((r >> 1) & 7);                                                          \
+    so_a0[i] = (uint32_t)(((size_t)min((m0_) + r, M - 1) * lda + c * 8) * 2);                           \
+    so_a1[i] = (uint32_t)(((size_t)min((m0_) + 128 + r, M - 1) * lda + c * 8) * 2);                     \
+    so_b0[i] = (uint32_t)(((size_t)min((n0_) + r, N - 1) * ldw + c * 8) * 2);                           \
+    so_b1[i] = (uint32_t)(((size_t)min((n0_) + 128 + r, N - 1) * ldw + c * 8) * 2);                     \
+  }
+  RR_SETUP_SRC(m0, n0)
+  const uint32_t lds_base = lds_addr(lds);
+  const int nk = Kd / BK, H = 4 * nk;
+  // half-tile (t, J): slot = parity (t&1) * 4 + J; J is a compile-time constant at every call site
+#define RR_DMA(t_, J)                                                                                             \
+  {                                                                                                               \
+    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(A + (size_t)(t_) * BK) : (const void*)(W + (size_t)(t_) * BK); \
+    const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
+    glds16_so(sb_, so_[0], dst_);                                                                                 \
+    glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
+  }
+  // wait until half-tile h_need (and everything older) has landed; h_last = newest half-tile issued so far
+  auto wait_half = [&](int h_need, int h_last) {
+    if (h_need >= H) return;
+    const int after = h_last - h_need;                        // half-tiles issued after the needed one
+    if (after >= 3) wait_vmcnt<6>();
+    else if (after == 2) wait_vmcnt<4>();
+    else if (after == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+  };
+
+  // ---- fragment addresses inside a half-tile slot (swizzle term is the same for every 16-row block); the two
+  // 32-deep k-steps of a fragment differ by chunk ^ 4 = byte offset ^ 64
+  const int a_off = swz128(wr * 64 + (lane & 15), lane >> 4);
+  const int b_off = swz128(wc * 32 + (lane & 15), lane >> 4);
+  auto read_a = [&](const char* slot, int ks, bf16x8 (&f)[4]) {
+    const char* b = slot + (ks ? (a_off ^ 64) : a_off);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) f[mt] = *(const bf16x8*)(b + mt * 2048);
+  };
+  auto read_b = [&](const char* slot, int ks, bf16x8 (&f)[2]) {
+    const char* b = slot + (ks ? (b_off ^ 64) : b_off);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(b + nt * 2048);
+  };
+
+  f32x4 acc[4][2][4];   // [quadrant 2*hA+hB][nt][mt]; lane: m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg
+
+  // Register fragments: A of the current row half (both k-steps), B0 (kept p0..p3) and B1 (p1..p2).  Fragments for a
+  // k-step are fetched one 8-MFMA block ahead of their use, so nothing is double-buffered: 64 fragment + 128
+  // accumulator registers.
+  bf16x8 AF0[4], AF1[4], B0K0[2], B0K1[2], B1K0[2], B1K1[2];
+
+#define RR_BLK(Q, AF, BF)                                                                          \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
+      acc[Q][nt][mt] = mfma16<DT>(BF[nt], AF[mt], acc[Q][nt][mt]);
+#define RR_SBAR() __builtin_amdgcn_sched_barrier(0)
+  // wave priority falls with progress inside a barrier interval: of the two waves that share a SIMD the one that is
+  // BEHIND wins the MFMA pipe, so they advance together instead of the older wave racing ahead to idle at the barrier
+#define RR_PRIO(p) __builtin_amdgcn_s_setprio(p);
+
+  // ---- first output tile: cold prologue, half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3})
+  RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
+  if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
+  bool first_tile = true;
+  for (;;) {                                                // one iteration per output tile of this workgroup
+  // all of K-tile 0 landed (my pieces).  After the first output tile the queue holds [g0..g4, the previous epilogue's
+  // loads/stores, g5, g6]: the same literal then also retires that epilogue's stores.
+  if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  if (first_tile && nk > 1) { /* cold queue is [g0..g6]: vmcnt(4) leaves g5, g6 -> g4 landed as well, harmless */ }
+  __builtin_amdgcn_s_barrier();
+  if (first_tile) stamp(stamps, 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  read_a(lds + 0 * HALF, 0, AF0);
+  read_b(lds + 1 * HALF, 0, B0K0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1]));
+
+  // Diagnostic build (DIAG): per-wave s_memtime marks inside every phase, summed over the loop and written to
+  // stamps[block][8 + wave*8 + k]; the marks are read only after the phase's own lgkmcnt(0), so they add no wait.
+  unsigned long long dg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tmk[9];
+#define RR_MARK(k) { if constexpr (DIAG) { RR_SBAR(); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); RR_SBAR(); } }
+#define RR_ACC(base, n)                                                                       \
+  {                                                                                           \
+    if constexpr (DIAG) {                                                                     \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) dg[(base) + k_] += tmk[k_ + 1] - tmk[k_]; \
+    }                                                                                         \
+  }
+  // sync point with marks m0 (before), m0+1 (after the vmcnt wait), m0+2 (after lgkmcnt(0)), m0+3 (after the barrier).
+  // In the steady state the wait is a literal (no scalar branch cascade in the loop body).
+#define RR_SYNC(STEADY, NLIT, g_need, g_last, m0)        \
+  {                                                      \
+    RR_SBAR();                                           \
+    RR_MARK(m0)                                          \
+    if (STEADY) wait_vmcnt<NLIT>();                      \
+    else wait_half(g_need, g_last);                      \
+    RR_MARK((m0) + 1)                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    RR_MARK((m0) + 2)                                    \
+    __builtin_amdgcn_s_barrier();                        \
+    RR_SBAR();                                           \
+    RR_MARK((m0) + 3)                                    \
+  }
+
+  // Two barriers per K-tile.  X (end of p1): A0/B0 of the next tile have landed and every wave is done with this
+  // tile's A0, B0, B1 slots; Y (end of p3): B1/A1 of the next tile have landed and every wave is done with this tile's
+  // A1 slot.  p0 and p2 end without a barrier: what they hand to p1 / p3 was covered by the previous Y / X.  (Four
+  // barriers, one per phase, cost 17 % more main-loop cycles.)  Refills: p0 A1(t+1); p2 A0(t+2), B0(t+2); p3 B1(t+2) —
+  // the g order the counted waits rely on.  Measured and NOT better: one barrier per tile (the refill window shrinks
+  // to one tile and the drained DMA sets the pace), an LDS arrive/poll counter instead of s_barrier (s_barrier itself
+  // is ~36 cycles, tools/barrier_probe.hip), one 1-KiB piece per 8-MFMA block instead of pairs (a piece costs its wave
+  // ~60 cycles wherever it sits), all pieces moved by the younger wave of each SIMD pair under EXEC masking (-10 %).
+  // RR_TILE(1) is the steady state (t <= nk-3): every refill exists and the vmcnt waits are literals, so the body is
+  // straight-line code; RR_TILE(0) handles the last two tiles with the general guards.
+#define RR_TILE(STEADY)                                                                                    \
+  {                                                                                                        \
+    const char* sl = lds + (t & 1) * 4 * HALF;               /* this tile's slots: +0 A0, +1 B0, +2 B1, +3 A1 */ \
+    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;         /* next tile's */                              \
+    const bool d1 = ((STEADY) || t + 1 < nk) && !no_dma, d2 = ((STEADY) || t + 2 < nk) && !no_dma;          \
+    /* ---- p0: quadrant (A0, B0) */                                                                        \
+    RR_MARK(0)                                                                                             \
+    read_a(sl + 0 * HALF, 1, AF1);                                                                         \
+    read_b(sl + 1 * HALF, 1, B0K1);                                                                        \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(3)                                                                                             \
+    RR_BLK(0, AF0, B0K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(1)                                                                                             \
+    read_b(sl + 2 * HALF, 0, B1K0);                                                                        \
+    if (d1) RR_DMA(t + 1, 3)                                 /* A1 of the next tile (slot free since Y(t-1)) */ \
+    RR_SBAR();                                                                                             \
+    RR_MARK(2)                                                                                             \
+    RR_PRIO(2)                                                                                             \
+    RR_BLK(0, AF1, B0K1)                                                                                   \
+    RR_SBAR();                                                                                             \
+    /* ---- p1: quadrant (A0, B1) */                                                                        \
+    RR_MARK(3)                                                                                             \
+    read_b(sl + 2 * HALF, 1, B1K1);                                                                        \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(1)                                                                                             \
+    RR_BLK(1, AF0, B1K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(4)                                                                                             \
+    read_a(sl + 3 * HALF, 0, AF0);                                                                         \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(0)                                                                                             \
+    RR_BLK(1, AF1, B1K1)                                                                                   \
+    RR_SYNC(STEADY, 4, 4 * (t + 1) + 1, min(H - 1, 4 * (t + 1) + 3), 5)   /* X: A0(t+1), B0(t+1) landed */    \
+    RR_ACC(0, 8)                                                                                           \
+    /* ---- p2: quadrant (A1, B1) */                                                                        \
+    RR_MARK(0)                                                                                             \
+    read_a(sl + 3 * HALF, 1, AF1);                                                                         \
+    if (d2) RR_DMA(t + 2, 0)                                 /* slots A0, B0 (free since X) */               \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(3)                                                                                             \
+    RR_BLK(3, AF0, B1K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    if (d2) RR_DMA(t + 2, 1)                                                                               \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(2)                                                                                             \
+    RR_BLK(3, AF1, B1K1)                                                                                   \
+    RR_SBAR();                                                                                             \
+    RR_MARK(1)                                                                                             \
+    /* ---- p3: quadrant (A1, B0) */                                                                        \
+    RR_PRIO(1)                                                                                             \
+    RR_BLK(2, AF0, B0K0)                                                                                   \
+    RR_SBAR();                                                                                             \
+    if ((STEADY) || t + 1 < nk) {                                                                          \
+      read_a(sn + 0 * HALF, 0, AF0);                                                                       \
+      read_b(sn + 1 * HALF, 0, B0K0);                                                                      \
+    }                                                                                                      \
+    if (d2) RR_DMA(t + 2, 2)                                 /* slot B1 (free since X) */                    \
+    RR_SBAR();                                                                                             \
+    RR_PRIO(0)                                                                                             \
+    RR_BLK(2, AF1, B0K1)                                                                                   \
+    RR_SYNC(STEADY, 6, 4 * (t + 1) + 3, min(H - 1, 4 * (t + 2) + 2), 2)   /* Y: B1(t+1), A1(t+1) landed */    \
+    /* The next tile's first fragments are complete here (lgkmcnt(0) above).  Tell the compiler: otherwise it    \
+       treats them as pending across the back edge and puts lgkmcnt(0) behind the six ds_reads that open p0. */  \
+    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1])); \
+    RR_ACC(8, 5)                                                                                           \
+  }
+  const bool no_dma = DIAG && stagger_unit == 61;            // diagnostic: main loop without refills (wrong results)
+  int t = 0;
+  for (; t < nk - 2; ++t) RR_TILE(1)
+  for (; t < nk; ++t) RR_TILE(0)
+#undef RR_TILE
+  if constexpr (DIAG) {
+    if (stamps && lane == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned long long* o = stamps + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 16;
+      for (int k = 0; k < 13; ++k) o[k] = dg[k];
+    }
+  }
+#undef RR_SYNC
+#undef RR_MARK
+#undef RR_ACC
+  wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
+  if (first_tile) stamp(stamps, 2);
+
+  // ---- next output tile of this workgroup: request its first five half-tiles into ring slots 0-4 now (every slot has
+  // been free since the last barrier of the main loop); the epilogue below works in the upper LDS half only
+  const int cm0 = m0, cn0 = n0;                             // the tile being written out
+  li += gstep;
+  const bool has_next = li < chunk_n;
+  if (has_next) {
+    const int tile = chunk0 + li, tm = tile / tiles_n;
+    m0 = tm * BM;
+    n0 = (tile - tm * tiles_n) * BN;
+    RR_SETUP_SRC(m0, n0)
+    RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
+    if (nk > 1) RR_DMA(1, 0)
+  }
+
+  // ---- epilogue of tile (cm0, cn0), staged through the UPPER LDS half [5 * HALF, 160 KiB): 16-bit output in two 128-row
+  // passes (pass = hA), fp32 in four 64-row passes (pass = 2*hA + wr: one wave row group at a time)
+  constexpr bool F32_OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32);
+  {
+    constexpr int ES = F32_OUT ? 4 : 2;
+    constexpr int PITCH = BN * ES + 16;
+    constexpr int CPR = BN * ES / 16;
+    constexpr int NPASS = F32_OUT ? 4 : 2;
+    constexpr int ROWS = F32_OUT ? 64 : 128;
+    static_assert(ROWS * PITCH <= 5 * HALF, "staging image must fit above the five prefetch slots");
+    char* const stg = lds + 5 * HALF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hB = q & 1;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int gn = cn0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+        const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
+                v3 = acc[q][nt][mt][3] + bv.w;
+          if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+          if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+          if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+          acc[q][nt][mt] = f32x4{v0, v1, v2, v3};
+        }
+      }
+    }
+    const int my_col = cn0 + (tid % CPR) * (16 / ES);
+    float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_BIAS_RESID_F32 && ln.stats && my_col < N) {
+      lg = *(const float4*)(ln.gamma + my_col);
+      lb = *(const float4*)(ln.beta + my_col);
+    }
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int hA = q >> 1, hB = q & 1;
+        if (F32_OUT ? (hA != (pass >> 1) || wr != (pass & 1)) : (hA != pass)) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int cn = hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int r = (F32_OUT ? 0 : wr * 64) + mt * 16 + (lane & 15);
+            char* dst = stg + r * PITCH + cn * ES;
+            if constexpr (F32_OUT) *(f32x4*)dst = acc[q][nt][mt];
+            else *(uint2*)dst = make_uint2(pack2<DT>(acc[q][nt][mt][0], acc[q][nt][mt][1]),
+                                           pack2<DT>(acc[q][nt][mt][2], acc[q][nt][mt][3]));
+          }
+        }
+      }
+      __syncthreads();
+      const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
+      // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
+      // add/store (a wave keeps one row per step: its LayerNorm statistics are a scalar load)
+      constexpr int UNR = 8;
+      static_assert(512 % CPR == 0 && ROWS * CPR == 512 * UNR, "one batch per pass; a wave must not straddle rows");
+      float4 rv[UNR];
+      if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
+          const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
+          const bool ok = gm < M && gcol < N;
+          float4 x = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ln.stats) {
+            const int gm_s = __builtin_amdgcn_readfirstlane(min(gm, M - 1));     // wave-uniform row
+            const float2 st2 = ln.stats[gm_s];
+            x = make_float4((x.x - st2.x) * st2.y * lg.x + lb.x, (x.y - st2.x) * st2.y * lg.y + lb.y,
+                            (x.z - st2.x) * st2.y * lg.z + lb.z, (x.w - st2.x) * st2.y * lg.w + lb.w);
+          }
+          rv[u] = x;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
+        const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
+        if (gm < M && gcol < N) {
+          uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
+          if (EPI == EPI_BIAS_RESID_F32) {
+            float4 f = __builtin_bit_cast(float4, v);
+            f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
+            v = __builtin_bit_cast(uint4, f);
+          }
+          *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+        }
+      }
+      __syncthreads();                                       // staging image consumed (next pass / next tile may overwrite it)
+    }
+  }
+  if (first_tile) stamp(stamps, 3);
+  first_tile = false;
+  if (!has_next) break;
+  if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) }                 // slots 5, 6 were under the staging image until now
+  }   // output tiles
+#undef RR_SETUP_SRC
+#undef RR_DMA
+#undef RR_BLK
+#undef RR_SBAR
+}
+
+
+
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
 int g_variant = -1;                      // tuning override (rr_set_gemm_variant); -1: shape heuristic
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
+int g_persistent = 1;                     // rr_set_tuning("persistent_gemm"): 1 = variant 14 for large problems, 0 = variant 12
+
+// persistent variant: one workgroup per CU (160 KiB of LDS each), grid = number of CUs rounded down to a multiple of 8
+template <int DT>
+hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                     int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
+  if (N & 7) return hipErrorInvalidValue;
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
+    n_cu = prop.multiProcessorCount & ~7;
+  }
+  if (n_cu < 8) return hipErrorInvalidValue;
+  constexpr int lds_bytes = 160 * 1024;
+  dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
+  unsigned long long* stamps = g_stamps;
+#define RR_GEMM_CASE(E)                                                                                       \
+  case E: {                                                                                                   \
+    auto kern = gemm_kernel_hp<E, DT>;                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      if (e != hipSuccess) return e;                                                                          \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
+                       tiles_n, nwg, stamps, ln, 0);                                                          \
+    break;                                                                                                    \
+  }
+  switch (epilogue) {
+    RR_GEMM_CASE(EPI_BIAS_BF16)
+    RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
+    RR_GEMM_CASE(EPI_BIAS_F32)
+    RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
+    RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
+    default: return hipErrorInvalidValue;
+  }
+#undef RR_GEMM_CASE
+  return hipGetLastError();
+}
 
 template <bool LDS_EPI, int DT>
 hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
@@ -1111,8 +1514,12 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 13) return -1;
+  if (v < -1 || v > 14) return -1;
   g_variant = v;
+  return 0;
+}
+extern "C" int rr_set_gemm_persistent(int on) {
+  g_persistent = on != 0;
   return 0;
 }
 extern "C" int rr_set_gemm_stagger(int unit) {
@@ -1155,10 +1562,10 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   }
   int v = g_variant;
   if (v < 0) {
-    // big problems: 256x256 tiles, half-tile LDS ring (variant H) with the LDS-staged coalesced epilogue; small ones:
+    // big problems: 256x256 tiles, persistent half-tile LDS ring (variant HP) with the LDS-staged coalesced epilogue; small ones:
     // 128x128 so the grid still fills 256 CUs (measured with tools/bench_gemm.py --stamps, profiles/).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    v = tiles256 >= 512 ? ((N & 7) ? 11 : 12) : 0;
+    v = tiles256 >= 512 ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
   }
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
@@ -1167,6 +1574,7 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
       case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 14: return launch_hp<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       default: return hipErrorInvalidValue;
     }
   }
@@ -1186,6 +1594,7 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
     case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 12:
     case 13: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 14: return launch_hp<0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     default: return hipErrorInvalidValue;
   }
