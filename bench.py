@@ -206,7 +206,7 @@ def main():
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_h (16-bit MFMA GEMM, half-tile LDS ring, fused epilogues; all GEMM launches of the step)",
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_hp (16-bit MFMA GEMM, persistent half-tile LDS ring, fused epilogues; all GEMM launches of the step)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_gb("gemm"),
                                "traffic_unit": "GB per launch beyond L2 (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
