@@ -277,10 +277,11 @@ int rr_op_gemm_ln_resid_f32(const uint16_t* A, const uint16_t* W, const float* b
 int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
                          const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out,
                          int out_stride, void* hip_stream);
-/* Tuning hooks (tools/bench_gemm.py). rr_set_gemm_variant forces a tile configuration: 0..3 = "simple" loop
- * {128x128x2st, 128x128x4st, 256x256x2st, 256x128x3st}, 4..7 = "pipelined" loop {128x128x2st, 128x128x3st,
- * 256x256x2st, 256x128x3st}; -1 = shape heuristic (default).  rr_set_gemm_stamps: DEVICE buffer of 4 uint64
- * per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
+/* Tuning hooks (tools/bench_gemm.py). rr_set_gemm_variant forces a kernel / tile configuration: 0..3 = gemm_kernel_s
+ * {128x128x2st, 128x128x4st, 256x256x2st, 256x128x3st} with the direct epilogue, 10 = 256x256x2st with the LDS-staged
+ * epilogue, 11 / 12 = gemm_kernel_h (half-tile ring) with the direct / LDS-staged epilogue, 13 = its diagnostic timeline
+ * build, 14 = gemm_kernel_hp (persistent ring); -1 = shape heuristic (default).  rr_set_gemm_stamps: DEVICE buffer of
+ * 8 uint64 per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
  * Both are process-wide and diagnostic. */
 int rr_set_gemm_variant(int variant);
 int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1) */

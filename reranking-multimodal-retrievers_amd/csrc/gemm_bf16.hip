@@ -14,8 +14,10 @@
 //   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): the LDS image is lane-linear,
 //     the XOR bank swizzle is applied on the per-lane SOURCE address and again on the ds_read_b128
 //     (cdna_hip_programming.md §5.4 rule 21);
-//   * STAGES-deep ring of K-tiles, one raw s_barrier per K-tile, counted s_waitcnt vmcnt(N) that leaves
-//     the STAGES-2 youngest tiles in flight across the barrier (never a drain in the steady state);
+//   * three kernels: gemm_kernel_s (128x128..256x256, STAGES-deep ring of whole K-tiles, one barrier per K-tile) for
+//     small problems, gemm_kernel_h (256x256, ring of 8 half-tile slots, two barriers per K-tile) and gemm_kernel_hp
+//     (the same loop, persistent: one workgroup per CU, the next tile's prologue requested behind the epilogue) for
+//     large ones; counted s_waitcnt vmcnt(N) literals keep the youngest refills in flight across the barriers;
 //   * the MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so each
 //     lane ends up with 4 consecutive output columns of one output row: bias/GELU/residual epilogues
 //     work on float4 and stores are 8/16-byte vectors;
@@ -115,174 +117,6 @@ __device__ __forceinline__ void start_stagger(int first_wave, int unit_sleeps) {
 
 __device__ __forceinline__ void stamp(unsigned long long* stamps, int slot) {
   if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
-}
-
-// Variant P ("pipelined"): 32x32x16 MFMA, two register fragment sets ping-ponged per 16-deep k-step, the tile
-// barrier in the middle of the MFMA stream.
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_p(const bf16_t* __restrict__ A, int lda,
-                                                             const bf16_t* __restrict__ W, int ldw,
-                                                             const float* __restrict__ bias,
-                                                             const float* __restrict__ resid, int ldr,
-                                                             void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                             int tiles_n, int nwg, unsigned long long* stamps,
-                                                             int stagger_unit, LnResid ln) {
-  if (stagger_unit > 0) start_stagger(256, stagger_unit);
-  stamp(stamps, 0);
-  constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
-  constexpr int MT = TM / 32, NT = TN / 32;            // 32x32 MFMA tiles per wave
-  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;
-  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;    // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile
-  constexpr int PIECES = PA + PW;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into whole pieces per wave");
-  static_assert(TM % 32 == 0 && TN % 32 == 0, "per-wave tile must be a multiple of the 32x32 MFMA");
-  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-  extern __shared__ __attribute__((aligned(16))) char lds[];   // STAGES * STAGE_BYTES, the only LDS object
-
-  // ---- XCD-aware bijective block remap: blocks b, b+8, ... share an XCD (round-robin dispatch);
-  // give each XCD a contiguous run of tiles.
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;   // n fastest: A panel reused from L2
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  // ---- staging sources: lane -> (row, 16-byte chunk) of each of this wave's pieces
-  const bf16_t* a_src[PA];
-  const bf16_t* w_src[PW];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int r = (wave * PA + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);              // source chunk that lands in slot lane&7
-    a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;   // clamp: padded rows re-read a valid row
-  }
-#pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    const int r = (wave * PW + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    w_src[i] = W + (size_t)min(n0 + r, N - 1) * ldw + c * 8;
-  }
-  const uint32_t lds_base = lds_addr(lds);
-  auto stage = [&](int buf, int k0) {
-    const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * PA * 1024);
-    const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + A_BYTES + wave * PW * 1024);
-#pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(a_src[i] + k0, a_dst + i * 1024);
-#pragma unroll
-    for (int i = 0; i < PW; ++i) glds16(w_src[i] + k0, w_dst + i * 1024);
-  };
-
-  // ---- fragment addressing: lane reads row (lane&31) of a 32-row block, chunk 2*s + (lane>>5) of k16-step s.
-  // The swizzle term (row>>1)&7 does not depend on the 32-row block index, so block mt is a +4096 immediate.
-  const int r32 = lane & 31, hh = lane >> 5;
-  const int a_row = wm * TM + r32, w_row = wn * TN + r32;
-  const int a_x = (a_row >> 1) & 7, w_x = (w_row >> 1) & 7;
-  auto load_frags = [&](const char* tile_base, int s, bf16x8 (&af)[MT], bf16x8 (&wf)[NT]) {
-    const char* ab = tile_base + a_row * 128 + (((2 * s + hh) ^ a_x) << 4);
-    const char* wb = tile_base + A_BYTES + w_row * 128 + (((2 * s + hh) ^ w_x) << 4);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(wb + t * 4096);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(ab + t * 4096);
-  };
-
-  f32x16 acc[NT][MT];   // lane holds m = mt*32 + (lane&31), n = nt*32 + (r&3) + 8(r>>2) + 4(lane>>5)
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = Kd / BK;
-#pragma unroll
-  for (int s = 0; s < STAGES; ++s)
-    if (s < nk) stage(s, s * BK);
-
-  bf16x8 afA[MT], wfA[NT], afB[MT], wfB[NT];   // two register fragment sets (k16-step ping-pong)
-  wait_tiles<PIECES, STAGES - 1>(min(nk, STAGES) - 1);   // tile 0 landed
-  __builtin_amdgcn_s_barrier();
-  stamp(stamps, 1);
-  load_frags(lds, 0, afA, wfA);
-
-#define RR_MFMA_BLOCK(AF, WF)                                                                        \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) \
-      acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[nt], AF[mt], acc[nt][mt], 0, 0, 0);
-
-  // The sched_barriers pin "issue the next step's 6 LDS reads, THEN this step's MFMAs": the reads' latency is
-  // covered by a whole MFMA block instead of being waited for right before use.
-#define RR_SB() __builtin_amdgcn_sched_barrier(0)
-#define RR_STEPS_0_TO_2(tb)        \
-  load_frags(tb, 1, afB, wfB);     \
-  RR_SB();                         \
-  RR_MFMA_BLOCK(afA, wfA)          \
-  RR_SB();                         \
-  load_frags(tb, 2, afA, wfA);     \
-  RR_SB();                         \
-  RR_MFMA_BLOCK(afB, wfB)          \
-  RR_SB();                         \
-  load_frags(tb, 3, afB, wfB);     \
-  RR_SB();                         \
-  RR_MFMA_BLOCK(afA, wfA)          \
-  RR_SB();
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    const char* tb = lds + (kt % STAGES) * STAGE_BYTES;
-    RR_STEPS_0_TO_2(tb)
-    // tile kt+1 must have landed; tiles kt+2 .. min(nk-1, kt+STAGES-1) may stay in flight
-    wait_tiles<PIECES, STAGES - 2>(min(nk - 1, kt + STAGES - 1) - (kt + 1));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of tile kt are complete ...
-    __builtin_amdgcn_s_barrier();                        // ... and everyone's: its buffer may be refilled
-    if (kt + STAGES < nk) stage(kt % STAGES, (kt + STAGES) * BK);
-    load_frags(lds + ((kt + 1) % STAGES) * STAGE_BYTES, 0, afA, wfA);
-    RR_SB();
-    RR_MFMA_BLOCK(afB, wfB)
-    RR_SB();
-  }
-  {   // last K-tile: nothing left to prefetch
-    const char* tb = lds + ((nk - 1) % STAGES) * STAGE_BYTES;
-    RR_STEPS_0_TO_2(tb)
-    RR_MFMA_BLOCK(afB, wfB)
-  }
-#undef RR_STEPS_0_TO_2
-  stamp(stamps, 2);
-#undef RR_SB
-#undef RR_MFMA_BLOCK
-
-  // ---- epilogue: per 32x32 tile a lane owns row m and 4 groups of 4 consecutive columns
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int gn = n0 + wn * TN + nt * 32 + 8 * g + 4 * hh;
-      if (gn >= N) continue;
-      const float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int gm = m0 + wm * TM + mt * 32 + r32;
-        if (gm >= M) continue;
-        float v0 = acc[nt][mt][4 * g + 0] + bv.x, v1 = acc[nt][mt][4 * g + 1] + bv.y,
-              v2 = acc[nt][mt][4 * g + 2] + bv.z, v3 = acc[nt][mt][4 * g + 3] + bv.w;
-        if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-        if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
-        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-        if (EPI == EPI_BIAS_RESID_F32) {
-          const float4 rv = *(const float4*)(resid + (size_t)gm * ldr + gn);
-          v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-        }
-        if (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32) {
-          *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
-        } else {
-          *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-        }
-      }
-    }
-  }
-  stamp(stamps, 3);
 }
 
 // Variant S ("simple"): 16x16x32 MFMA, tile barrier at the top of each K-tile, fragment reads scheduled by the
@@ -475,143 +309,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       }
     }
   }
-  }
-  stamp(stamps, 3);
-}
-
-// Variant G ("group-staggered"): 256x256x32 K-tiles in a STAGES-deep LDS ring (32 KiB each), 8 waves as two
-// groups (waves 0-3 / 4-7 = the two waves of every SIMD).  Every K-tile has a LOAD segment (12 ds_read_b128 +
-// this wave's 4 DMA pieces for the tile STAGES-1 ahead) and a COMPUTE segment (32 MFMAs) separated by barriers,
-// and group 1 runs one barrier behind group 0: while one wave of a SIMD issues MFMAs its partner reads LDS, so
-// the matrix pipe never waits for fragment loads, and the DMA of a tile has STAGES-2 full iterations to land
-// (MI355X_MICROARCH.md "Two waves per SIMD").  Hazards: RAW — every wave waits (counted vmcnt) for its pieces
-// of tile j before the barrier that precedes the first read of tile j; WAR — tile j-1's buffer is refilled
-// only in LOAD(j), i.e. after the barrier that follows group 1's lgkmcnt(0) of LOAD(j-1).  Both groups execute
-// exactly 2*nk+1 barriers.
-__device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4); }
-
-template <int STAGES, int EPI>
-__global__ __launch_bounds__(512) void gemm_kernel_g(const bf16_t* __restrict__ A, int lda,
-                                                     const bf16_t* __restrict__ W, int ldw,
-                                                     const float* __restrict__ bias,
-                                                     const float* __restrict__ resid, int ldr,
-                                                     void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                     int tiles_n, int nwg, unsigned long long* stamps, LnResid ln) {
-  stamp(stamps, 0);
-  constexpr int BM = 256, BN = 256, BKG = 32, WN = 4;
-  constexpr int TM = 128, TN = 64, MT = 8, NT = 4;
-  constexpr int A_BYTES = BM * BKG * 2, STAGE_BYTES = (BM + BN) * BKG * 2;   // 16 KiB + 16 KiB
-  constexpr int PIECES = 4;                                                   // 2 A + 2 W pieces (16 rows x 64 B) per wave
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                       // 0: waves 0-3, 1: waves 4-7
-  const int wm = wave / WN, wn = wave % WN;
-
-  // staging: piece p of this wave = rows (wave*2 + p)*16 .. +15, lane -> (row = lane>>2, slot = lane&3)
-  const bf16_t* a_src[2];
-  const bf16_t* w_src[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wave * 2 + i) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
-    a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
-    w_src[i] = W + (size_t)min(n0 + r, N - 1) * ldw + c * 8;
-  }
-  const uint32_t lds_base = lds_addr(lds);
-  auto stage = [&](int buf, int k0) {
-    const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 2048);
-    const uint32_t w_dst = a_dst + A_BYTES;
-    glds16(a_src[0] + k0, a_dst);
-    glds16(a_src[1] + k0, a_dst + 1024);
-    glds16(w_src[0] + k0, w_dst);
-    glds16(w_src[1] + k0, w_dst + 1024);
-  };
-  const int nk = Kd / BKG;
-  auto wait_for_tile = [&](int j) {                 // my pieces of tile j have landed
-    const int inflight = min(nk - 1, j + STAGES - 2) - j;
-    if (inflight >= 3) wait_vmcnt<3 * PIECES>();
-    else if (inflight == 2) wait_vmcnt<2 * PIECES>();
-    else if (inflight == 1) wait_vmcnt<PIECES>();
-    else wait_vmcnt<0>();
-  };
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) stage(s, s * BKG);
-
-  // fragment addresses: lane reads row (lane&15) of a 16-row block, chunk lane>>4; the swizzle term is the same
-  // for every 16-row block, so block t is a +1024-byte immediate
-  const int a_off = swz64(wm * TM + (lane & 15), lane >> 4);
-  const int w_off = A_BYTES + swz64(wn * TN + (lane & 15), lane >> 4);
-
-  if (grp == 1) {
-    wait_for_tile(0);
-    __builtin_amdgcn_s_barrier();                   // stagger: group 1 runs one barrier behind
-  }
-  for (int j = 0; j < nk; ++j) {
-    if (grp == 0) wait_for_tile(j);
-    __builtin_amdgcn_s_barrier();                   // B1(j)
-    if (j == 0) stamp(stamps, 1);
-    const char* tb = lds + (j % STAGES) * STAGE_BYTES;
-    bf16x8 af[MT], wf[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wf[t] = *(const bf16x8*)(tb + w_off + t * 1024);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) af[t] = *(const bf16x8*)(tb + a_off + t * 1024);
-    if (j + STAGES - 1 < nk) stage((j + STAGES - 1) % STAGES, (j + STAGES - 1) * BKG);
-    if (grp == 1 && j + 1 < nk) wait_for_tile(j + 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                   // B2(j)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();       // both groups: 2*nk + 1 barriers
-  stamp(stamps, 2);
-
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
-    if (gn >= N) continue;
-    float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int gm = m0 + wm * TM + mt * 16 + (lane & 15);
-      if (gm >= M) continue;
-      float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
-            v3 = acc[nt][mt][3] + bv.w;
-      if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      if (EPI == EPI_BIAS_RESID_F32) {
-        const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gn), ln, gm, gn);
-        v0 += rv.x; v1 += rv.y; v2 += rv.z; v3 += rv.w;
-      }
-      if (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32) {
-        *(float4*)((float*)Cv + (size_t)gm * ldc + gn) = make_float4(v0, v1, v2, v3);
-      } else {
-        *(uint2*)((bf16_t*)Cv + (size_t)gm * ldc + gn) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-      }
-    }
   }
   stamp(stamps, 3);
 }
@@ -1435,42 +1132,7 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
 }
 
 
-template <int STAGES>
-hipError_t launch_g(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
-                    int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
-  if (Kd % 32 != 0) return hipErrorInvalidValue;
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
-  constexpr int lds_bytes = STAGES * 512 * 32 * 2;
-  dim3 grid(nwg), block(512);
-  unsigned long long* stamps = g_stamps;
-#define RR_GEMM_CASE(E)                                                                                       \
-  case E: {                                                                                                   \
-    auto kern = gemm_kernel_g<STAGES, E>;                                                                     \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-      if (e != hipSuccess) return e;                                                                          \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln);                                                             \
-    break;                                                                                                    \
-  }
-  switch (epilogue) {
-    RR_GEMM_CASE(EPI_BIAS_BF16)
-    RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
-    RR_GEMM_CASE(EPI_BIAS_F32)
-    RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
-    RR_GEMM_CASE(EPI_BIAS_RESID_F32)
-    RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
-    default: return hipErrorInvalidValue;
-  }
-#undef RR_GEMM_CASE
-  return hipGetLastError();
-}
-
-
-template <int BM, int BN, int WM, int WN, int STAGES, bool PIPE, bool LDS_EPI = false, int DT = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, bool LDS_EPI = false, int DT = 0>
 hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
                       int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
@@ -1485,7 +1147,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
   unsigned long long* stamps = g_stamps;
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
-    auto kern = PIPE ? gemm_kernel_p<BM, BN, WM, WN, STAGES, E> : gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI, DT>;                                                       \
+    auto kern = gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI, DT>;                                        \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -1569,33 +1231,27 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   }
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
-      case 0: return launch_cfg<128, 128, 2, 2, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-      case 2: return launch_cfg<256, 256, 2, 4, 2, false, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-      case 10: return launch_cfg<256, 256, 2, 4, 2, false, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 2: return launch_cfg<256, 256, 2, 4, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 10: return launch_cfg<256, 256, 2, 4, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 14: return launch_hp<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       default: return hipErrorInvalidValue;
     }
   }
-#define RR_CFG(BM_, BN_, WM_, WN_, ST_, P_) \
-  return launch_cfg<BM_, BN_, WM_, WN_, ST_, P_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln)
+#define RR_CFG(BM_, BN_, WM_, WN_, ST_) \
+  return launch_cfg<BM_, BN_, WM_, WN_, ST_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln)
   switch (v) {
-    case 0: RR_CFG(128, 128, 2, 2, 2, false);
-    case 1: RR_CFG(128, 128, 2, 2, 4, false);
-    case 2: RR_CFG(256, 256, 2, 4, 2, false);
-    case 3: RR_CFG(256, 128, 4, 2, 3, false);
-    case 4: RR_CFG(128, 128, 2, 2, 2, true);
-    case 5: RR_CFG(128, 128, 2, 2, 3, true);
-    case 6: RR_CFG(256, 256, 2, 4, 2, true);
-    case 7: RR_CFG(256, 128, 4, 2, 3, true);
-    case 8: return launch_g<4>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-    case 10: return launch_cfg<256, 256, 2, 4, 2, false, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 0: RR_CFG(128, 128, 2, 2, 2);
+    case 1: RR_CFG(128, 128, 2, 2, 4);
+    case 2: RR_CFG(256, 256, 2, 4, 2);
+    case 3: RR_CFG(256, 128, 4, 2, 3);
+    case 10: return launch_cfg<256, 256, 2, 4, 2, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 11: return launch_h<false, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 12:
     case 13: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 14: return launch_hp<0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-    case 9: return launch_g<5>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     default: return hipErrorInvalidValue;
   }
 #undef RR_CFG

@@ -247,7 +247,7 @@ def test_fp16_operand_ops(lib):
 
 # ---- every tile configuration behind rr_set_gemm_variant, the production half-tile-ring kernel (11 direct / 12 LDS
 # epilogue) included: the shape heuristic only picks it at >= 512 output tiles, so it is forced here on ragged shapes
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 10, 11, 12, 14])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_variant_every_epilogue(lib, variant, epi):
     shapes = [(1000, 768, 768), (515, 2304, 768), (257, 200, 3072), (64, 64, 64)]

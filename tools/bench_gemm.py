@@ -15,7 +15,7 @@ from rmr_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=800)
 ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--variants", default="2,10,11,12")
+ap.add_argument("--variants", default="2,10,12,14")
 ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--stagger", default="0")
 ap.add_argument("--no-check", action="store_true")
