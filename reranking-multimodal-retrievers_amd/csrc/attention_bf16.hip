@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        int Tq, int Tk, bf16_t* __restrict__ out,
                                                        int out_stride, int groups,
                                                        const float* __restrict__ dense_bias, int dense_ld,
-                                                       unsigned long long* __restrict__ stamps) {
+                                                       unsigned long long* __restrict__ stamps, int g_attn_prio) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const float* bt_ = b_img + buf * KT;
 
     // ---- S^T tile: keys 0..31 -> s0, 32..63 -> s1; reg r <-> key (r&3) + 8(r>>2) + 4h
+    if (g_attn_prio) __builtin_amdgcn_s_setprio(2);   // MFMA sections outrank the softmax VALU of the co-resident waves
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       s0 = mfma32<DT>(k0, qf[i], s0);
       s1 = mfma32<DT>(k1, qf[i], s1);
     }
+    if (g_attn_prio) __builtin_amdgcn_s_setprio(0);
     RR_MARK(1)
     // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
     // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
+    if (g_attn_prio) __builtin_amdgcn_s_setprio(2);
     RR_MARK(2)
     // ---- O^T += V^T P^T.  P fragment for k-step s of key block kb = regs 8s..8s+7 (k order:
     // element j <-> key 16 s + 8 (j>>2) + 4 h + (j&3)); V fragment gathers the same keys.
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         o1 = mfma32<DT>(v1, pf, o1);
       }
     }
+    if (g_attn_prio) __builtin_amdgcn_s_setprio(0);
     RR_MARK(3)
     if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
     RR_MARK(4)
@@ -268,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }  // namespace
 
 static unsigned long long* g_attn_stamps = nullptr;
+static int g_attn_prio_host = 1;   // rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention)
+extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on; return 0; }
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
   return 0;
@@ -286,10 +292,10 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
 #define RR_ATTN(DT_, DENSE_)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<DT_, DENSE_>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, \
-                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, nullptr)
+                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, nullptr, g_attn_prio_host)
   if (g_attn_stamps && dt == 0 && !dense_bias) {   // diagnostic timeline (tools/attn_timeline.py)
     hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v,
-                       kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, g_attn_stamps);
+                       kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, g_attn_stamps, g_attn_prio_host);
     return hipGetLastError();
   }
   if (dt == 0) { if (dense_bias) RR_ATTN(0, true); else RR_ATTN(0, false); }
