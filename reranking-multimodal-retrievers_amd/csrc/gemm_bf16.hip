@@ -45,6 +45,15 @@ __device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint
       : "memory");
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), i.e. waits for every global
+// store / LDS-DMA in flight — between the passes of the staged epilogue that would stall on the previous pass's
+// stores (and, in the persistent kernel, on the next tile's prefetch)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       const int row_base = m0 + (F32_OUT ? pass * TM : 0);
 #pragma unroll 4
       for (int i = tid; i < ROWS * CPR; i += NTHR) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
           *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
         }
       }
-      if (pass + 1 < NPASS) __syncthreads();
+      if (pass + 1 < NPASS) lds_barrier();
     }
   } else {
 #pragma unroll
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       const int row_base = m0 + (F32_OUT ? pass * 128 : 0);
       // stream the staged rows out, UNR 16-byte chunks per thread in flight at a time: the residual loads of a whole
       // batch are issued before the first add/store so that ~64-128 KiB per CU are outstanding (the 4-deep form ran
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
           }
         }
       }
-      if (pass + 1 < NPASS) __syncthreads();
+      if (pass + 1 < NPASS) lds_barrier();
     }
   } else {
 #pragma unroll
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
       // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
       // add/store (a wave keeps one row per step: its LayerNorm statistics are a scalar load)
@@ -1034,7 +1043,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
         }
       }
-      __syncthreads();                                       // staging image consumed (next pass / next tile may overwrite it)
+      lds_barrier();                                       // staging image consumed (next pass / next tile may overwrite it)
     }
   }
   if (first_tile) stamp(stamps, 3);
