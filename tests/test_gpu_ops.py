@@ -347,3 +347,30 @@ def test_ln_residual_gemm_is_reproducible_and_matches_materialised_residual(lib,
             assert len(bad) == 0, f"variant {variant}: {len(bad)} elements differ, first {bad[:4].tolist()}"
     finally:
         lib.rr_set_gemm_variant(-1)
+
+
+@pytest.mark.parametrize("variant", [12, 14])
+@pytest.mark.parametrize("M,N,K", [(70001, 1000, 128), (33 * 256 + 5, 2304, 64), (256 * 300, 768, 192), (65537, 264, 320)])
+def test_ring_kernels_ragged_multi_tile(lib, variant, M, N, K):
+    """The ring kernels at sizes where a persistent workgroup walks several tiles, with ragged last row/column tiles and
+    one- to five-tile K loops (steady-state loop, guarded tail and the K-tile-0-only case), against fp32 torch."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda()
+    ref = A.float() @ W.float().t() + b
+    try:
+        assert lib.rr_set_gemm_variant(variant) == 0
+        out16 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, 0, out16.data_ptr(), _stream()) == 0
+        out32 = torch.full((M, N), float("nan"), device="cuda")
+        assert lib.rr_op_gemm_resid_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), M, N, K, out32.data_ptr(),
+                                        _stream()) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.rr_set_gemm_variant(-1)
+    e16 = (out16.float() - ref).abs()
+    assert torch.isfinite(out16.float()).all() and (e16 <= 1.2e-2 * (1 + ref.abs())).all(), e16.max().item()
+    e32 = (out32 - (ref + R)).abs()
+    assert torch.isfinite(out32).all() and (e32 <= 2e-4 * (1 + ref.abs())).all(), e32.max().item()
