@@ -215,6 +215,16 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
                            int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
                            float* scores_out, int32_t* order_out, void* hip_stream);
 
+/* rr_forward_interaction_fusion: the same with the PreFLMR attention fusion of InteractionRerankModel.forward
+ * (interaction_rerank_model.py:131-142; NORMAL interaction type only, MORES raises NotImplementedError,
+ * mores_model.py:72-73): preflmr_scores DEVICE float32 [N, Lc, Lq] (context token x query token) becomes the additive
+ * bias [[0, softmax(scores^T)], [softmax(scores), 0]] * fusion_multiplier over the tokens [query | context]. */
+int rr_forward_interaction_fusion(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                                  const float* context_mask, const float* preflmr_scores, float fusion_multiplier, int Bq,
+                                  int K, int Lq, int Lc, const float* labels, int pair_begin, int pair_end,
+                                  float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
+                                  int32_t* order_out, void* hip_stream);
+
 /* rr_head: scoring head + loss + top-K order over complete logits [Bq*K] (after the RCCL
  * all-gather of per-rank slices).  Same semantics as the tail of rr_forward. */
 int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,

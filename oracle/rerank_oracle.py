@@ -474,9 +474,11 @@ def mores_layer(h: Tensor, doc: Tensor, w: Dict[str, Tensor], p: str, heads: int
 
 def interaction_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_li: Tensor, context_li: Tensor,
                         query_mask: Tensor, context_mask: Tensor, K: int, labels: Optional[List[float]] = None,
-                        mores: bool = False, mm=None, want_taps: bool = False) -> OracleOutput:
-    """`InteractionRerankModel.forward` (interaction_rerank_model.py:110-166) without attention fusion.
-    query_li [Bq,Lq,D], context_li [N,Lc,D], masks 0/1 [Bq,Lq] / [N,Lc]."""
+                        mores: bool = False, mm=None, want_taps: bool = False,
+                        preflmr_scores: Optional[Tensor] = None, fusion_multiplier: float = 1.0) -> OracleOutput:
+    """`InteractionRerankModel.forward` (interaction_rerank_model.py:110-166).
+    query_li [Bq,Lq,D], context_li [N,Lc,D], masks 0/1 [Bq,Lq] / [N,Lc]; `preflmr_scores` [N,Lc,Lq] adds the attention
+    fusion bias (:131-142; NORMAL interaction type only, MORES raises NotImplementedError, mores_model.py:72-73)."""
     Bq = query_li.shape[0]
     N = Bq * K
     assert N == context_li.shape[0], f"{query_li.shape}, {context_li.shape}, {K - 1}"          # :123
@@ -484,6 +486,15 @@ def interaction_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_li: Tenso
     qm = query_mask.to(torch.float32).repeat_interleave(K, dim=0)                                  # :129
     cm = context_mask.to(torch.float32)
     taps = {} if want_taps else None
+    adj = None
+    if preflmr_scores is not None:                                                                  # :131-142
+        if mores:
+            raise NotImplementedError("Attention adj is not implemented for MORES")
+        Lq, Lc = query_li.shape[1], context_li.shape[1]
+        ur = torch.softmax(preflmr_scores.permute(0, 2, 1), dim=-1)
+        bl = torch.softmax(preflmr_scores, dim=-1)
+        adj = torch.cat([torch.cat([torch.zeros(N, Lq, Lq), ur], 2), torch.cat([bl, torch.zeros(N, Lc, Lc)], 2)], 1) \
+            * fusion_multiplier
     if mores:                                                                                       # :147-156
         h = linear(q, w, "cross_encoder_input_mapping", mm)
         doc = linear(context_li.to(torch.float32), w, "cross_encoder_input_mapping", mm)
@@ -494,7 +505,7 @@ def interaction_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_li: Tenso
         l1, l2 = linear(cls, w, "reranker.classifier1"), linear(cls, w, "reranker.classifier2")
     else:                                                                                           # :157-161
         x = linear(torch.cat((q, context_li), dim=1), w, "cross_encoder_input_mapping", mm)
-        l1, l2 = cross_encoder(cfg, w, x, torch.cat((qm, cm), dim=1), None, mm, taps)
+        l1, l2 = cross_encoder(cfg, w, x, torch.cat((qm, cm), dim=1), adj, mm, taps)
     logits, lab = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)                     # :163
     loss = loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)                                     # :164
     if cfg.loss_fn == "2H_BCE":      # the reference returns both columns here (:165); ranking uses column 1 everywhere else

@@ -66,6 +66,8 @@ _SIGS = {
                                           C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "rr_forward_interaction": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                          _P, _P, _P, _P, _P, _P]),
+    "rr_forward_interaction_fusion": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+                                                C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "rr_head": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "rr_debug_read": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "rr_set_debug": (C.c_int, [_P, C.c_int]),

@@ -271,11 +271,13 @@ __global__ __launch_bounds__(256) void vit_embed_ln_kernel(const float* __restri
 //   adj[Tq + kc][j < Tq] = mult * softmax over j  of ts[kc][j]      (context row attends query)
 //   0 elsewhere (the two self-attention blocks, and the padding columns up to ld), with ts[kc][*] = scores[2 + kc][*],
 //   kc < Tc = S - ql.  One workgroup per pair.
+// `row0` = first score row that belongs to the sequence (2 for the joint RerankModel sequence, 0 for the Interaction
+// reranker, interaction_rerank_model.py:131-142, whose scores are [N, Lc, Lq] already).
 __global__ __launch_bounds__(256) void fusion_adj_kernel(const float* __restrict__ scores, int S, int Tq, int Tc, float mult,
-                                                         int pair0, float* __restrict__ adj, int ld) {
+                                                         int pair0, float* __restrict__ adj, int ld, int row0) {
   extern __shared__ float colstat[];                 // [Tq] max, [Tq] 1/sum
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* ts = scores + ((size_t)(pair0 + b) * S + 2) * Tq;
+  const float* ts = scores + ((size_t)(pair0 + b) * S + row0) * Tq;
   float* A = adj + (size_t)b * (Tq + Tc) * ld;
   for (int i = tid; i < Tq; i += 256) {              // column statistics (softmax over the context tokens)
     float mx = -INFINITY;
@@ -445,9 +447,10 @@ hipError_t rr_launch_vit_embed_ln(const float* patches, const float* cls_emb, co
 }
 
 hipError_t rr_launch_fusion_adj(const float* scores, int S, int Tq, int Tc, float mult, int pair0, int n, float* adj, int ld,
-                                hipStream_t st) {
-  if (n <= 0 || Tq <= 0 || Tc <= 0 || 2 + Tc > S || ld < Tq + Tc || (ld & 63) || Tq > 8192) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fusion_adj_kernel, dim3(n), dim3(256), 2 * Tq * sizeof(float), st, scores, S, Tq, Tc, mult, pair0, adj, ld);
+                                hipStream_t st, int row0) {
+  if (n <= 0 || Tq <= 0 || Tc <= 0 || row0 < 0 || row0 + Tc > S || ld < Tq + Tc || (ld & 63) || Tq > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fusion_adj_kernel, dim3(n), dim3(256), 2 * Tq * sizeof(float), st, scores, S, Tq, Tc, mult, pair0, adj, ld,
+                     row0);
   return hipGetLastError();
 }
 

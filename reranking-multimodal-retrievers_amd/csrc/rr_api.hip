@@ -597,6 +597,15 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   return RR_OK;
 }
 
+// grow-only buffer of the attention-fusion bias [n][T][ld]
+int ensure_adj(rr_model* m, size_t bytes, hipStream_t st) {
+  if (bytes <= m->adj_cap) return RR_OK;
+  if (m->adj) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->adj)); m->adj = nullptr; m->adj_cap = 0; }
+  RR_HIP(m, hipMalloc((void**)&m->adj, bytes));
+  m->adj_cap = bytes;
+  return RR_OK;
+}
+
 // CLS heads + (when this call covers every pair) the scoring head.  classifier1 -> "logits", classifier2 ->
 // "logits_secondary" (utils.py:105-108); for 2H_BCE the ranked logit is the second head (rerank_model.py:589-590).
 int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K, int pair_begin, bool full,
@@ -1113,11 +1122,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     if (!joint) return fail(m, RR_ERR_BAD_ARG, "attention fusion belongs to the joint (RerankModel) forward");
     adj_ld = (T + 63) / 64 * 64;
     const size_t need_adj = (size_t)n * T * adj_ld * sizeof(float);
-    if (need_adj > m->adj_cap) {
-      if (m->adj) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->adj)); m->adj = nullptr; m->adj_cap = 0; }
-      RR_HIP(m, hipMalloc((void**)&m->adj, need_adj));
-      m->adj_cap = need_adj;
-    }
+    RR_TRY(ensure_adj(m, need_adj, st));
     RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * (double)S * (q_len + P) + (double)need_adj,
            rr_launch_fusion_adj(preflmr_scores, S, q_len + P, S - q_len, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st));
     adj = m->adj;
@@ -1159,10 +1164,11 @@ int rr_forward_joint_fusion(rr_handle h, const int64_t* joint_input_ids, const i
 /* InteractionRerankModel.forward (interaction_rerank_model.py:110-166) from the retriever's late-interaction
  * tensors.  NORMAL: cat(query, context) -> Linear -> CrossEncoder; MORES (mores_model.py:21-94): Lc layers of
  * cross-attention(query -> doc) -> self-attention -> FFN over the query tokens. */
-int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
-                           const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
-                           int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
-                           float* scores_out, int32_t* order_out, void* hip_stream) {
+static int forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                               const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
+                               int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                               float* scores_out, int32_t* order_out, void* hip_stream, const float* preflmr_scores,
+                               float fusion_multiplier) {
   if (!h) return RR_ERR_BAD_ARG;
   rr_model* m = h;
   const rr_config& c = m->cfg;
@@ -1208,10 +1214,21 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
   m->tap_li_elems = (size_t)n * T * D;
 
   if (c.model_kind == RR_MODEL_INTERACTION) {
-    RR_TRY(run_cross_encoder(m, st, w, n, T));
+    const float* adj = nullptr;
+    int adj_ld = 0;
+    if (preflmr_scores) {   // interaction_rerank_model.py:131-142: scores [N, Lc, Lq] over the tokens [query | context]
+      adj_ld = (T + 63) / 64 * 64;
+      const size_t need_adj = (size_t)n * T * adj_ld * sizeof(float);
+      RR_TRY(ensure_adj(m, need_adj, st));
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * (double)Lc * Lq + (double)need_adj,
+             rr_launch_fusion_adj(preflmr_scores, Lc, Lq, Lc, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st, 0));
+      adj = m->adj;
+    }
+    RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld));
     return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
                      order_out);
   }
+  if (preflmr_scores) return fail(m, RR_ERR_UNSUPPORTED, "Attention adj is not implemented for MORES");   // mores_model.py:72-73
 
   // ---- MORES: hidden = Linear(query) [n*Lq, Hc] (no embeddings, no LayerNorm), doc = Linear(context) [n*Lc, Hc]
   // gather the two token groups out of the concatenated 16-bit buffer into contiguous GEMM operands
@@ -1252,6 +1269,25 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
   m->tap_ce_elems = (size_t)n * Lq * Hc;
   return run_heads(m, st, w, n, Lq, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
                    order_out);
+}
+
+int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                           const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
+                           int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
+                           float* scores_out, int32_t* order_out, void* hip_stream) {
+  return forward_interaction(h, query_li, context_li, query_mask, context_mask, Bq, K, Lq, Lc, labels, pair_begin, pair_end,
+                             logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, nullptr, 1.0f);
+}
+
+int rr_forward_interaction_fusion(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+                                  const float* context_mask, const float* preflmr_scores, float fusion_multiplier, int Bq,
+                                  int K, int Lq, int Lc, const float* labels, int pair_begin, int pair_end,
+                                  float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
+                                  int32_t* order_out, void* hip_stream) {
+  if (h && !preflmr_scores) return fail(h, RR_ERR_BAD_ARG, "rr_forward_interaction_fusion: preflmr_scores is null");
+  return forward_interaction(h, query_li, context_li, query_mask, context_mask, Bq, K, Lq, Lc, labels, pair_begin, pair_end,
+                             logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, preflmr_scores,
+                             fusion_multiplier);
 }
 
 int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems) {

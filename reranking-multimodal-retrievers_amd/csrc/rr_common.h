@@ -115,7 +115,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
                                hipStream_t st, const float* dense_bias = nullptr, int dense_ld = 0);
 // dense_bias: optional additive bias [B][Tq][dense_ld] (dense_ld a multiple of 64 >= Tk, zero padded), PreFLMR fusion
 hipError_t rr_launch_fusion_adj(const float* scores, int S, int Tq, int Tc, float mult, int pair0, int n, float* adj, int ld,
-                                hipStream_t st);
+                                hipStream_t st, int row0 = 2);
 
 // CLIP ViT front end: im2col of the stride = kernel patch convolution, and [class | patches] + position -> pre_layrnorm
 hipError_t rr_launch_vit_im2col(const float* px, bf16_t* out, int B, int IS, int ps, int Kp, int dt, hipStream_t st);

@@ -359,8 +359,10 @@ class RerankEngine:
     def forward_interaction(self, query_li: torch.Tensor, context_li: torch.Tensor, query_mask: torch.Tensor,
                             context_mask: torch.Tensor, Bq: int, K: int, labels: Optional[torch.Tensor] = None,
                             want_scores: bool = False, want_order: bool = False,
-                            pair_range: Optional[Sequence[int]] = None, want_loss: bool = True):
-        """Interaction rerankers: late-interaction tensors [Bq,Lq,D] / [N,Lc,D] and 0/1 masks [Bq,Lq] / [N,Lc]."""
+                            pair_range: Optional[Sequence[int]] = None, want_loss: bool = True,
+                            preflmr_scores: Optional[torch.Tensor] = None, fusion_multiplier: float = 1.0):
+        """Interaction rerankers: late-interaction tensors [Bq,Lq,D] / [N,Lc,D] and 0/1 masks [Bq,Lq] / [N,Lc];
+        `preflmr_scores` [N, Lc, Lq] switches the attention fusion on (rr_forward_interaction_fusion)."""
         dev = self.device
         N = context_li.shape[0]
         assert N == Bq * K and query_li.shape[0] == Bq, \
@@ -381,10 +383,20 @@ class RerankEngine:
         scores = torch.empty(N, **f32) if (full and want_scores) else None
         order = torch.empty((Bq, K), dtype=torch.int32, device=dev) if (full and want_order) else None
         stream = torch.cuda.current_stream(dev).cuda_stream
-        L.check(self.lib.rr_forward_interaction(self.h, L.ptr(query_li), L.ptr(context_li), L.ptr(query_mask),
-                                                L.ptr(context_mask), Bq, K, Lq, Lc, L.ptr(labels), pb, pe,
-                                                L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
-                                                L.ptr(order), stream), self.h, "rr_forward_interaction")
+        if preflmr_scores is not None:
+            ps = preflmr_scores.to(**f32).contiguous()
+            if tuple(ps.shape) != (N, Lc, Lq):
+                raise AssertionError(f"preflmr_scores must be [{N}, {Lc}, {Lq}], got {tuple(ps.shape)}")
+            L.check(self.lib.rr_forward_interaction_fusion(self.h, L.ptr(query_li), L.ptr(context_li), L.ptr(query_mask),
+                                                           L.ptr(context_mask), L.ptr(ps), float(fusion_multiplier), Bq, K,
+                                                           Lq, Lc, L.ptr(labels), pb, pe, L.ptr(logits), L.ptr(logits2),
+                                                           L.ptr(loss), L.ptr(scores), L.ptr(order), stream),
+                    self.h, "rr_forward_interaction_fusion")
+        else:
+            L.check(self.lib.rr_forward_interaction(self.h, L.ptr(query_li), L.ptr(context_li), L.ptr(query_mask),
+                                                    L.ptr(context_mask), Bq, K, Lq, Lc, L.ptr(labels), pb, pe,
+                                                    L.ptr(logits), L.ptr(logits2), L.ptr(loss), L.ptr(scores),
+                                                    L.ptr(order), stream), self.h, "rr_forward_interaction")
         return dict(logits=logits, logits2=logits2, loss=loss, scores=scores, order=order)
 
     def head(self, logits: torch.Tensor, logits2: Optional[torch.Tensor], labels: Optional[torch.Tensor], Bq: int,
@@ -550,8 +562,6 @@ class InteractionRerankModel(torch.nn.Module):
 
     def forward(self, query_late_interaction, context_late_interaction, num_negative_examples, query_mask,
                 context_mask, preflmr_scores=None, fusion_multiplier=1, labels=None, **kw) -> RerankOutput:
-        if preflmr_scores is not None:
-            raise NotImplementedError("Attention adj (preflmr_scores) is not implemented on this path")
         K = num_negative_examples + 1
         Bq = query_late_interaction.size(0)
         N = context_late_interaction.size(0)
@@ -564,7 +574,8 @@ class InteractionRerankModel(torch.nn.Module):
                 raise AssertionError("Labels should not be provided for negative sampling loss function")
             labels_t = torch.tensor(labels, dtype=torch.float32, device=self.engine.device)
         r = self.engine.forward_interaction(query_late_interaction, context_late_interaction, query_mask, context_mask,
-                                            Bq, K, labels_t, **kw)
+                                            Bq, K, labels_t, preflmr_scores=preflmr_scores,
+                                            fusion_multiplier=float(fusion_multiplier), **kw)
         logits = r["logits"]
         logits = logits.view(Bq, K) if arch["loss_fn"] == "negative_sampling" else logits.view(N, 1)
         out = RerankOutput(loss=r["loss"], logits=logits)

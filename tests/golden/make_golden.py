@@ -136,7 +136,7 @@ class HFInteraction:
         return torch.nn.functional.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"))
 
     @torch.no_grad()
-    def forward(self, q, c, qm, cm, K, labels):
+    def forward(self, q, c, qm, cm, K, labels, scores=None, mult=1.0):
         cfg = self.cfg
         Bq = q.shape[0]
         qq, qmm = q.repeat_interleave(K, 0), qm.repeat_interleave(K, 0)
@@ -153,7 +153,15 @@ class HFInteraction:
             cls = h[:, 0]
         else:
             x = self.lin(torch.cat((qq, c), 1), "cross_encoder_input_mapping")
-            cls = self.ce(inputs_embeds=x, attention_mask=torch.cat((qmm, cm), 1)).last_hidden_state[:, 0]
+            m01 = torch.cat((qmm, cm), 1)
+            if scores is None:
+                cls = self.ce(inputs_embeds=x, attention_mask=m01).last_hidden_state[:, 0]
+            else:     # attention fusion (interaction_rerank_model.py:131-142): stock BertEncoder on the additive 4-D mask
+                N, Lq, Lc = x.shape[0], q.shape[1], c.shape[1]
+                ur, bl = torch.softmax(scores.permute(0, 2, 1), -1), torch.softmax(scores, -1)
+                adj = torch.cat([torch.cat([torch.zeros(N, Lq, Lq), ur], 2), torch.cat([bl, torch.zeros(N, Lc, Lc)], 2)], 1) * mult
+                ext = (1.0 - m01)[:, None, None, :] * torch.finfo(torch.float32).min + adj[:, None]
+                cls = self.ce.encoder(self.ce.embeddings(inputs_embeds=x), attention_mask=ext).last_hidden_state[:, 0]
         l1, l2 = self.lin(cls, "reranker.classifier1"), self.lin(cls, "reranker.classifier2")
         logits, lab = O.prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, labels)
         loss = O.loss_value(cfg.loss_fn, cfg.pos_weight, logits, lab)
@@ -272,6 +280,8 @@ INTERACTION_CASES = {
                  2, 3, 9, 40, False, "BCE"),
     "mores_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
                    2, 3, 9, 40, True, "negative_sampling"),
+    "int_fuse_tiny": (dict(ce_hidden=128, ce_heads=2, ce_intermediate=512, ce_layers=2, ce_max_pos=128, li_dim=64),
+                      2, 3, 9, 40, False, "BCE"),                             # + PreFLMR attention fusion
     "int_base": (dict(ce_layers=3), 1, 6, 113, 512, False, "BCE"),          # ModPreFLMR-BERT shape, K cut to 6
     "mores_base": (dict(ce_layers=5), 1, 6, 113, 512, True, "BCE"),         # ModPreFLMR-IB shape
 }
@@ -287,8 +297,12 @@ def run_interaction_case(name, outdir):
     if loss != "negative_sampling":
         rng = np.random.Generator(np.random.PCG64(5))
         labels = [float(x) for x in (rng.random(Bq * K) < 0.3)]
-    loss_hf, logits_hf = HFInteraction(cfg, w, mores).forward(q, c, qm, cm, K, labels)
-    out = O.interaction_forward(cfg, w, q, c, qm, cm, K, labels, mores)
+    scores, mult = None, 1.0
+    if "fuse" in name:
+        scores = 3.0 * torch.randn(Bq * K, Lc, Lq, generator=torch.Generator().manual_seed(77))
+        mult = 20.0
+    loss_hf, logits_hf = HFInteraction(cfg, w, mores).forward(q, c, qm, cm, K, labels, scores, mult)
+    out = O.interaction_forward(cfg, w, q, c, qm, cm, K, labels, mores, preflmr_scores=scores, fusion_multiplier=mult)
     d_logit = (out.logits - logits_hf).abs().max().item()
     d_loss = (out.loss - loss_hf).abs().item()
     print(f"[{name}] oracle-vs-HF: logits {d_logit:.3e} loss {d_loss:.3e}")
@@ -298,7 +312,9 @@ def run_interaction_case(name, outdir):
                         query_mask=qm.numpy(), context_mask=cm.numpy(),
                         labels=np.array(labels if labels is not None else [], dtype=np.float32),
                         logits=logits_hf.numpy(), loss=np.array(loss_hf.item(), dtype=np.float32),
-                        order=np.array(order, dtype=np.int32), oracle_vs_hf=np.array([d_logit, d_loss]))
+                        order=np.array(order, dtype=np.int32), oracle_vs_hf=np.array([d_logit, d_loss]),
+                        preflmr_scores=(scores.numpy() if scores is not None else np.zeros(0, dtype=np.float32)),
+                        fusion_multiplier=np.array(mult, dtype=np.float32))
 
 
 CASES = {

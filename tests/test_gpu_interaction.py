@@ -75,7 +75,7 @@ def test_module_interface_and_errors():
             context_mask=cm, labels=g["labels_list"])
     assert out.logits.shape == (g["Bq"] * g["K"], 1) and out.loss.dim() == 0
     assert abs(out.loss.item() - float(g["loss"])) < 1e-2
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                   # attention fusion scores must be [N, Lc, Lq]
         m(q, c, g["K"] - 1, qm, cm, preflmr_scores=torch.zeros(1))
     with pytest.raises(AssertionError):
         m(q, c, g["K"], qm, cm)
@@ -95,3 +95,45 @@ def test_interaction_pair_slices_compose():
     b = eng.forward_interaction(*args, Bq, K, None, pair_range=(2, N), want_loss=False)["logits"][2:]
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([a, b]), full["logits"])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_interaction_attention_fusion(dtype):
+    """InteractionRerankModel.forward with `preflmr_scores` (interaction_rerank_model.py:131-142): device-built additive
+    bias over [query | context], against the stock-HF golden and the same-rounding oracle; MORES refuses it."""
+    import rmr_amd
+    g = _load("int_fuse_tiny")
+    g0 = _load("int_tiny")
+    cfg, Bq, K = g["cfg"], g["Bq"], g["K"]
+    w = O.make_interaction_weights(cfg, False, seed=0)
+    conf = dict(cross_encoder_num_hidden_layers=cfg.ce_layers, cross_encoder_max_position_embeddings=cfg.ce_max_pos,
+                loss_fn=cfg.loss_fn, interaction_type="NORMAL", arch=arch_from_cfg(cfg, False, dtype))
+    m = rmr_amd.InteractionRerankModel(conf, state_dict=w)
+    t = lambda k: torch.from_numpy(g[k])
+    mult = float(g["fusion_multiplier"])
+    out = m(t("query_li").cuda(), t("context_li").cuda(), K - 1, t("query_mask").cuda(), t("context_mask").cuda(),
+            preflmr_scores=t("preflmr_scores").cuda(), fusion_multiplier=mult, labels=g["labels_list"])
+    torch.cuda.synchronize()
+    gold = torch.from_numpy(g["logits"])
+    d = (out.logits.cpu() - gold).abs().max().item()
+    with torch.no_grad(), O.device_rounding(torch.bfloat16 if dtype == "bf16" else torch.float16) as mm:
+        emu = O.interaction_forward(cfg, w, t("query_li"), t("context_li"), t("query_mask"), t("context_mask"), K,
+                                    g["labels_list"], False, mm=mm, preflmr_scores=t("preflmr_scores"), fusion_multiplier=mult)
+    demu = (out.logits.cpu() - emu.logits).abs().max().item()
+    effect = (gold - torch.from_numpy(g0["logits"])).abs().max().item()
+    print(f"[int_fuse_tiny/{dtype}] |dlogit| vs fp32 golden {d:.2e}, vs same-rounding oracle {demu:.2e}; fusion moves the logits by {effect:.2e}")
+    assert effect > 5e-3 and d < (3e-4 if dtype == "fp16" else 1.5e-3) and demu < 3e-4
+    assert abs(out.loss.item() - float(g["loss"])) < 2e-3
+    with pytest.raises(AssertionError):                      # scores must be [N, Lc, Lq]
+        m(t("query_li").cuda(), t("context_li").cuda(), K - 1, t("query_mask").cuda(), t("context_mask").cuda(),
+          preflmr_scores=torch.zeros(2, 2, 2).cuda())
+    gm = _load("mores_tiny")
+    wm = O.make_interaction_weights(gm["cfg"], True, seed=0)
+    mm_ = rmr_amd.InteractionRerankModel(dict(cross_encoder_num_hidden_layers=gm["cfg"].ce_layers,
+                                              cross_encoder_max_position_embeddings=gm["cfg"].ce_max_pos,
+                                              loss_fn=gm["cfg"].loss_fn, interaction_type="MORES",
+                                              arch=arch_from_cfg(gm["cfg"], False, dtype)), state_dict=wm)
+    tm = lambda k: torch.from_numpy(gm[k]).cuda()
+    with pytest.raises(NotImplementedError):                 # mores_model.py:72-73
+        mm_(tm("query_li"), tm("context_li"), gm["K"] - 1, tm("query_mask"), tm("context_mask"),
+            preflmr_scores=torch.zeros(gm["Bq"] * gm["K"], gm["Lc"], gm["Lq"]).cuda())

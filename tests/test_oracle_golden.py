@@ -100,7 +100,7 @@ def test_flops_per_pair_matches_survey():
     assert O.flops_per_pair(cfg, 512, True) / 1e9 == pytest.approx(107.3, abs=0.5)    # c3
 
 
-@pytest.mark.parametrize("name", ["int_tiny", "mores_tiny"])
+@pytest.mark.parametrize("name", ["int_tiny", "mores_tiny", "int_fuse_tiny"])
 def test_interaction_oracle_matches_golden(name):
     import ast, os
     from helpers import GOLDEN
@@ -111,9 +111,11 @@ def test_interaction_oracle_matches_golden(name):
     w = O.make_interaction_weights(cfg, mores, seed=0)
     labels = [float(x) for x in z["labels"]] if z["labels"].size else None
     with torch.no_grad():
+        fuse = z["preflmr_scores"].size > 0
         out = O.interaction_forward(cfg, w, torch.from_numpy(z["query_li"]), torch.from_numpy(z["context_li"]),
                                     torch.from_numpy(z["query_mask"]), torch.from_numpy(z["context_mask"]), K, labels,
-                                    mores)
+                                    mores, preflmr_scores=torch.from_numpy(z["preflmr_scores"]) if fuse else None,
+                                    fusion_multiplier=float(z["fusion_multiplier"]))
     np.testing.assert_allclose(out.logits.numpy(), z["logits"], atol=2e-5, rtol=0)
     assert abs(out.loss.item() - float(z["loss"])) < 2e-5
     assert z["oracle_vs_hf"][0] < 1e-5
