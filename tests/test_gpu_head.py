@@ -77,9 +77,10 @@ def test_two_head_ce(pos_weight):
         eng.head(l2.reshape(-1).cuda(), None, None, Bq, K)                                # first head missing
 
 
-def test_listwise_head_and_limits():
+@pytest.mark.parametrize("Bq", [6, 64])                       # 64 queries x 100 candidates = BASELINE configs[3]
+def test_listwise_head_and_limits(Bq):
     eng = _engine("negative_sampling")
-    Bq, K = 6, 100
+    K = 100
     x = _logits(Bq, K, seed=5, ties=False)
     r = eng.head(x.reshape(-1).cuda(), None, None, Bq, K, want_scores=True)
     torch.cuda.synchronize()
