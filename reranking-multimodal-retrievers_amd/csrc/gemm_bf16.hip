@@ -801,11 +801,14 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
   bool first_tile = true;
   for (;;) {                                                // one iteration per output tile of this workgroup
-  // all of K-tile 0 landed (my pieces).  After the first output tile the queue holds [g0..g4, the previous epilogue's
-  // loads/stores, g5, g6]: the same literal then also retires that epilogue's stores.
-  if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
-  if (first_tile && nk > 1) { /* cold queue is [g0..g6]: vmcnt(4) leaves g5, g6 -> g4 landed as well, harmless */ }
-  __builtin_amdgcn_s_barrier();
+  // First output tile: all of K-tile 0 landed (my pieces; the cold queue is [g0..g6], vmcnt(4) leaves g5, g6), then the
+  // barrier.  Later tiles: every wave confirmed its pieces of the prefetched g0..g4 inside the previous epilogue — before
+  // that epilogue's first store, so that the wait never covers a store acknowledgement — and has passed workgroup
+  // barriers since: nothing to wait for here.
+  if (first_tile) {
+    if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+  }
   if (first_tile) stamp(stamps, 1);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -1006,6 +1009,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           }
         }
       }
+      // the next tile's prefetched half-tiles: confirm MY pieces now, while the only younger vector-memory operations
+      // are this epilogue's own loads (none issued yet in this pass) — not after the stores
+      if (pass == 0 && has_next) wait_vmcnt<0>();
       lds_barrier();
       const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
       // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
