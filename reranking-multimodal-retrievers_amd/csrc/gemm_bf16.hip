@@ -714,6 +714,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                                                      int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
                                                      int stagger_unit) {
   constexpr bool DIAG = false;
+  // row panels per group of the tile order (below): 8 for K <= 1024 (4 when the weight has more than 9 column slices),
+  // plain row-major for deeper K where one 256-row activation panel is already 1.5 MB (measured per shape with
+  // tools/bench_gemm.py --stagger 50..56: QKV +5 %, FFN-up +3 %, attention-out +2 % over row-major, FFN-down best as is)
+  const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50))      // A/B: 2..64
+                    : (stagger_unit == 56 || Kd > 1024) ? 1 : (tiles_n > 9 ? 4 : 8);
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -726,7 +731,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   int li = bid >> 3;
   if (li >= chunk_n) return;
   int m0, n0;
-  { const int tile = chunk0 + li, tm = tile / tiles_n; m0 = tm * BM; n0 = (tile - tm * tiles_n) * BN; }
+  // tile order inside the list: groups of GROUP row panels, column-major inside a group, so that the 32 tiles an XCD
+  // works on at a time are ~4 weight column slices x 8 activation row panels (each W slice is re-used 8 times out of
+  // L2 before it is evicted, instead of once per ~3 row panels with a row-major order)
+  const int tiles_m = nwg / tiles_n;
+  auto tile_origin = [&](int gidx, int& m0_, int& n0_) {
+    const int per_group = GROUP * tiles_n, grp = gidx / per_group, r = gidx - grp * per_group;
+    const int rows = min(GROUP, tiles_m - grp * GROUP);
+    const int tn = r / rows, tm = grp * GROUP + (r - tn * rows);
+    m0_ = tm * BM;
+    n0_ = tn * BN;
+  };
+  tile_origin(chunk0 + li, m0, n0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -948,9 +964,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   li += gstep;
   const bool has_next = li < chunk_n;
   if (has_next) {
-    const int tile = chunk0 + li, tm = tile / tiles_n;
-    m0 = tm * BM;
-    n0 = (tile - tm * tiles_n) * BN;
+    tile_origin(chunk0 + li, m0, n0);
     RR_SETUP_SRC(m0, n0)
     RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
     if (nk > 1) RR_DMA(1, 0)
@@ -1098,7 +1112,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, 0);                                                          \
+                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);                                   \
     break;                                                                                                    \
   }
   switch (epilogue) {
