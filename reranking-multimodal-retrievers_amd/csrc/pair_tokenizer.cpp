@@ -22,6 +22,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -319,30 +320,37 @@ struct rr_tokenizer {
 extern "C" {
 
 int rr_tok_create(const char* const* vocab_tokens, int vocab_size, int do_lower_case, rr_tokenizer_handle* out) {
-  if (!vocab_tokens || vocab_size <= 0 || !out) return RR_ERR_BAD_ARG;
-  *out = nullptr;
-  auto* t = new rr_tokenizer();
-  t->lower = do_lower_case != 0;
-  t->inv.reserve(vocab_size);
-  for (int i = 0; i < vocab_size; ++i) {
-    if (!vocab_tokens[i]) { delete t; return RR_ERR_BAD_ARG; }
-    std::string s(vocab_tokens[i]);
-    t->inv.push_back(s);
-    if (s.size() > 2 && s[0] == '#' && s[1] == '#') {
-      t->cont[s.substr(2)] = i;
-      t->max_piece_bytes = std::max(t->max_piece_bytes, s.size() - 2);
-    } else {
-      t->max_piece_bytes = std::max(t->max_piece_bytes, s.size());
+  try {
+    if (!vocab_tokens || vocab_size <= 0 || !out) return RR_ERR_BAD_ARG;
+    *out = nullptr;
+    auto* t = new rr_tokenizer();
+    t->lower = do_lower_case != 0;
+    t->inv.reserve(vocab_size);
+    for (int i = 0; i < vocab_size; ++i) {
+      if (!vocab_tokens[i]) { delete t; return RR_ERR_BAD_ARG; }
+      std::string s(vocab_tokens[i]);
+      t->inv.push_back(s);
+      if (s.size() > 2 && s[0] == '#' && s[1] == '#') {
+        t->cont[s.substr(2)] = i;
+        t->max_piece_bytes = std::max(t->max_piece_bytes, s.size() - 2);
+      } else {
+        t->max_piece_bytes = std::max(t->max_piece_bytes, s.size());
+      }
+      t->vocab[s] = i;                             // a repeated token keeps its LAST index, as load_vocab's dict does
     }
-    t->vocab[s] = i;                             // a repeated token keeps its LAST index, as load_vocab's dict does
+    auto id = [&](const char* s) { auto it = t->vocab.find(s); return it == t->vocab.end() ? -1 : it->second; };
+    t->unk = id("[UNK]"); t->cls = id("[CLS]"); t->sep = id("[SEP]"); t->pad = id("[PAD]");
+    if (t->unk < 0 || t->cls < 0 || t->sep < 0 || t->pad < 0) { delete t; return RR_ERR_MISSING_WEIGHT; }
+    for (const char* s : {"[UNK]", "[SEP]", "[PAD]", "[CLS]", "[MASK]"})
+      if (id(s) >= 0) t->special.emplace_back(s, id(s));
+    *out = t;
+    return RR_OK;
+  
+  } catch (const std::bad_alloc&) {
+    return RR_ERR_OOM;
+  } catch (...) {
+    return RR_ERR_BAD_ARG;   // no C++ exception crosses the C ABI
   }
-  auto id = [&](const char* s) { auto it = t->vocab.find(s); return it == t->vocab.end() ? -1 : it->second; };
-  t->unk = id("[UNK]"); t->cls = id("[CLS]"); t->sep = id("[SEP]"); t->pad = id("[PAD]");
-  if (t->unk < 0 || t->cls < 0 || t->sep < 0 || t->pad < 0) { delete t; return RR_ERR_MISSING_WEIGHT; }
-  for (const char* s : {"[UNK]", "[SEP]", "[PAD]", "[CLS]", "[MASK]"})
-    if (id(s) >= 0) t->special.emplace_back(s, id(s));
-  *out = t;
-  return RR_OK;
 }
 
 int rr_tok_destroy(rr_tokenizer_handle h) {
@@ -352,81 +360,102 @@ int rr_tok_destroy(rr_tokenizer_handle h) {
 }
 
 int rr_tok_encode(rr_tokenizer_handle h, const char* text, int max_tokens, int32_t* ids_out, int capacity) {
-  if (!h || !text || !ids_out || capacity < 0) return RR_ERR_BAD_ARG;
-  std::vector<int32_t> ids;
-  h->encode(text, strlen(text), ids);
-  if (max_tokens >= 0 && (int)ids.size() > max_tokens) ids.resize(max_tokens);
-  if ((int)ids.size() > capacity) return RR_ERR_BAD_SHAPE;
-  memcpy(ids_out, ids.data(), ids.size() * sizeof(int32_t));
-  return (int)ids.size();
+  try {
+    if (!h || !text || !ids_out || capacity < 0) return RR_ERR_BAD_ARG;
+    std::vector<int32_t> ids;
+    h->encode(text, strlen(text), ids);
+    if (max_tokens >= 0 && (int)ids.size() > max_tokens) ids.resize(max_tokens);
+    if ((int)ids.size() > capacity) return RR_ERR_BAD_SHAPE;
+    memcpy(ids_out, ids.data(), ids.size() * sizeof(int32_t));
+    return (int)ids.size();
+  
+  } catch (const std::bad_alloc&) {
+    return RR_ERR_OOM;
+  } catch (...) {
+    return RR_ERR_BAD_ARG;   // no C++ exception crosses the C ABI
+  }
 }
 
 int rr_tok_decode(rr_tokenizer_handle h, const int32_t* ids, int n, char* out, int capacity) {
-  if (!h || (!ids && n) || !out || n < 0 || capacity <= 0) return RR_ERR_BAD_ARG;
-  for (int i = 0; i < n; ++i)
-    if (ids[i] < 0 || (size_t)ids[i] >= h->inv.size()) return RR_ERR_BAD_ARG;
-  std::string s;
-  h->decode(ids, (size_t)n, s);
-  if ((int)s.size() + 1 > capacity) return RR_ERR_BAD_SHAPE;
-  memcpy(out, s.c_str(), s.size() + 1);
-  return (int)s.size();
+  try {
+    if (!h || (!ids && n) || !out || n < 0 || capacity <= 0) return RR_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i)
+      if (ids[i] < 0 || (size_t)ids[i] >= h->inv.size()) return RR_ERR_BAD_ARG;
+    std::string s;
+    h->decode(ids, (size_t)n, s);
+    if ((int)s.size() + 1 > capacity) return RR_ERR_BAD_SHAPE;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+  
+  } catch (const std::bad_alloc&) {
+    return RR_ERR_OOM;
+  } catch (...) {
+    return RR_ERR_BAD_ARG;   // no C++ exception crosses the C ABI
+  }
 }
 
 int rr_tok_prepare_pairs(rr_tokenizer_handle h, const char* const* queries, int n_queries, const char* const* contexts,
                          int docs_per_query, int max_query_length, int max_context_length, int max_length, int n_threads,
                          int64_t* input_ids, int64_t* attention_mask, int64_t* token_type_ids) {
-  if (!h || !queries || !contexts || !input_ids || !attention_mask || !token_type_ids) return RR_ERR_BAD_ARG;
-  if (n_queries <= 0 || docs_per_query <= 0 || max_query_length < 0 || max_context_length < 0 || max_length < 3)
-    return RR_ERR_BAD_SHAPE;
-  const size_t N = (size_t)n_queries * docs_per_query;
-  for (int i = 0; i < n_queries; ++i) if (!queries[i]) return RR_ERR_BAD_ARG;
-  for (size_t i = 0; i < N; ++i) if (!contexts[i]) return RR_ERR_BAD_ARG;
-  if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-  n_threads = (int)std::min<size_t>((size_t)n_threads, N);
-
-  // step 1: queries, truncated by the encode -> decode -> encode round trip (utils.py:131-136)
-  std::vector<std::vector<int32_t>> qids((size_t)n_queries);
-  {
-    std::vector<int32_t> ids;
-    std::string txt;
-    for (int i = 0; i < n_queries; ++i) {
-      h->encode(queries[i], strlen(queries[i]), ids);
-      if ((int)ids.size() > max_query_length) ids.resize(max_query_length);
-      h->decode(ids.data(), ids.size(), txt);
-      h->encode(txt.data(), txt.size(), qids[(size_t)i]);
+  try {
+    if (!h || !queries || !contexts || !input_ids || !attention_mask || !token_type_ids) return RR_ERR_BAD_ARG;
+    if (n_queries <= 0 || docs_per_query <= 0 || max_query_length < 0 || max_context_length < 0 || max_length < 3)
+      return RR_ERR_BAD_SHAPE;
+    const size_t N = (size_t)n_queries * docs_per_query;
+    for (int i = 0; i < n_queries; ++i) if (!queries[i]) return RR_ERR_BAD_ARG;
+    for (size_t i = 0; i < N; ++i) if (!contexts[i]) return RR_ERR_BAD_ARG;
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = (int)std::min<size_t>((size_t)n_threads, N);
+  
+    // step 1: queries, truncated by the encode -> decode -> encode round trip (utils.py:131-136)
+    std::vector<std::vector<int32_t>> qids((size_t)n_queries);
+    {
+      std::vector<int32_t> ids;
+      std::string txt;
+      for (int i = 0; i < n_queries; ++i) {
+        h->encode(queries[i], strlen(queries[i]), ids);
+        if ((int)ids.size() > max_query_length) ids.resize(max_query_length);
+        h->decode(ids.data(), ids.size(), txt);
+        h->encode(txt.data(), txt.size(), qids[(size_t)i]);
+      }
     }
+    // step 2: one work item per pair: context round trip (:139-144), pair encoding with LONGEST_FIRST truncation and
+    // right padding (:157-165)
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      std::vector<int32_t> ids, cids;
+      std::string txt;
+      for (;;) {
+        const size_t p = next.fetch_add(1);
+        if (p >= N) break;
+        h->encode(contexts[p], strlen(contexts[p]), ids);
+        if ((int)ids.size() > max_context_length) ids.resize(max_context_length);
+        h->decode(ids.data(), ids.size(), txt);
+        h->encode(txt.data(), txt.size(), cids);
+        const std::vector<int32_t>& q = qids[p / (size_t)docs_per_query];
+        size_t la = q.size(), lb = cids.size();
+        while (la + lb + 3 > (size_t)max_length) { if (la > lb) --la; else --lb; }
+        int64_t* I = input_ids + p * (size_t)max_length;
+        int64_t* A = attention_mask + p * (size_t)max_length;
+        int64_t* T = token_type_ids + p * (size_t)max_length;
+        size_t k = 0;
+        I[k] = h->cls; T[k++] = 0;
+        for (size_t i = 0; i < la; ++i) { I[k] = q[i]; T[k++] = 0; }
+        I[k] = h->sep; T[k++] = 0;
+        for (size_t i = 0; i < lb; ++i) { I[k] = cids[i]; T[k++] = 1; }
+        I[k] = h->sep; T[k++] = 1;
+        for (size_t i = 0; i < k; ++i) A[i] = 1;
+        for (; k < (size_t)max_length; ++k) { I[k] = h->pad; A[k] = 0; T[k] = 0; }
+      }
+    };
+    h->pool.run(n_threads, worker);
+    return RR_OK;
+  
+  } catch (const std::bad_alloc&) {
+    return RR_ERR_OOM;
+  } catch (...) {
+    return RR_ERR_BAD_ARG;   // no C++ exception crosses the C ABI
   }
-  // step 2: one work item per pair: context round trip (:139-144), pair encoding with LONGEST_FIRST truncation and
-  // right padding (:157-165)
-  std::atomic<size_t> next{0};
-  auto worker = [&]() {
-    std::vector<int32_t> ids, cids;
-    std::string txt;
-    for (;;) {
-      const size_t p = next.fetch_add(1);
-      if (p >= N) break;
-      h->encode(contexts[p], strlen(contexts[p]), ids);
-      if ((int)ids.size() > max_context_length) ids.resize(max_context_length);
-      h->decode(ids.data(), ids.size(), txt);
-      h->encode(txt.data(), txt.size(), cids);
-      const std::vector<int32_t>& q = qids[p / (size_t)docs_per_query];
-      size_t la = q.size(), lb = cids.size();
-      while (la + lb + 3 > (size_t)max_length) { if (la > lb) --la; else --lb; }
-      int64_t* I = input_ids + p * (size_t)max_length;
-      int64_t* A = attention_mask + p * (size_t)max_length;
-      int64_t* T = token_type_ids + p * (size_t)max_length;
-      size_t k = 0;
-      I[k] = h->cls; T[k++] = 0;
-      for (size_t i = 0; i < la; ++i) { I[k] = q[i]; T[k++] = 0; }
-      I[k] = h->sep; T[k++] = 0;
-      for (size_t i = 0; i < lb; ++i) { I[k] = cids[i]; T[k++] = 1; }
-      I[k] = h->sep; T[k++] = 1;
-      for (size_t i = 0; i < k; ++i) A[i] = 1;
-      for (; k < (size_t)max_length; ++k) { I[k] = h->pad; A[k] = 0; T[k] = 0; }
-    }
-  };
-  h->pool.run(n_threads, worker);
-  return RR_OK;
 }
 
 }  // extern "C"
