@@ -15,11 +15,20 @@
 //     "An accumulator tile as the next MFMA's operand") — P never touches LDS;
 //   * O^T = V^T P^T: V is staged row-major [key][d] in LDS (coalesced from HBM) and consumed
 //     column-major through ds_read_b64_tr_b16 (hardware transpose, T10);
-//   * K/V tiles of 64 keys are double-buffered in LDS through registers (issue-early/write-late, T14):
-//     the next tile's global loads are in flight under this tile's 16 MFMAs;
-//   * key padding: additive fp32 bias per key in the log2 domain (0 valid, -1e30 masked, -inf beyond
-//     Tk).  finfo.min-style semantics are preserved: a row with no valid key attends uniformly to
-//     all Tk keys exactly like softmax over a constant row does in the reference.
+//   * K/V tiles of 64 keys are double-buffered in LDS and arrive by LDS-DMA (global_load_lds_dwordx4, no staging
+//     registers; both swizzles applied on the global side): the next tile's 16 pieces are in flight under this tile's
+//     16 MFMAs;
+//   * key padding: additive fp32 bias per key (0 valid, -1e30 masked, -inf beyond Tk).  finfo.min-style semantics are
+//     preserved: a row with no valid key attends uniformly to all Tk keys exactly like softmax over a constant row
+//     does in the reference;
+//   * two schedules over the same tile code (attn_block): the online softmax, exact for any input, and the
+//     fixed-reference form (no running maximum, no O rescale; 128 VGPRs = 4 waves per SIMD) whose rare failures — a
+//     row sum beyond 2^64, a sequence without a valid key — are flagged per workgroup and recomputed online by a
+//     second, normally empty launch.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "rr_common.h"
 
 namespace {
@@ -47,155 +56,220 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* vt, int key0, int d_chunk_
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int DT, bool DENSE, bool DIAG = false>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ q, int q_stride,
-                                                       int q_batch_div, int q_batch_off,
-                                                       const bf16_t* __restrict__ k,
-                                                       const bf16_t* __restrict__ v, int kv_stride,
-                                                       const float* __restrict__ key_bias, int heads,
-                                                       int Tq, int Tk, bf16_t* __restrict__ out,
-                                                       int out_stride, int groups,
-                                                       const float* __restrict__ dense_bias, int dense_ld,
-                                                       unsigned long long* __restrict__ stamps, int g_attn_prio) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES + 2 * KT * 4 + 16];
+// a wave-uniform pointer the compiler cannot prove uniform: pin it to SGPRs (the LDS-DMA takes its base as an "s" operand)
+__device__ __forceinline__ const bf16_t* uniform_ptr(const bf16_t* p) {
+  const unsigned long long u = (unsigned long long)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return (const bf16_t*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+constexpr int ATTN_LDS_BYTES = 4 * TILE_BYTES + 2 * KT * 4 + 16;
+
+struct AttnArgs {
+  const bf16_t* q; int q_stride, q_batch_div, q_batch_off;
+  const bf16_t* k; const bf16_t* v; int kv_stride;
+  const float* key_bias; int heads, Tq, Tk;
+  bf16_t* out; int out_stride, groups;
+  const float* dense_bias; int dense_ld;
+  unsigned long long* stamps; int tuning;
+  int* flags; int nblk;      // fixed-reference schedule: one word per workgroup of the grid, 1 = recompute online
+};
+
+// One workgroup's share: 128 query rows of one (pair, head), block id `bid` of the launch grid.
+//   FIXED = false: online softmax (running max, O rescaled by exp(m_old - m_new) every tile) — exact for any input.
+//   FIXED = true : the exponentials are taken against a FIXED per-row reference (the row maximum of the first tile that
+//     holds a valid key) and the key bias is the initial value of the QK^T accumulators: no running maximum, no bias add,
+//     no O rescale — 138 VALU instructions per tile instead of ~205 on a kernel that is VALU-issue-bound (DESIGN.md
+//     §7.3), and 146 VGPRs.  softmax is shift-invariant and fp32 keeps its relative precision at any exponent, so the
+//     result differs from the online form in rounding only, as long as nothing overflows.  Returns true when it did not
+//     hold: a row sum left 2^64 (6e4 with fp16 operands; a later score far above the reference — inf and NaN fail the
+//     test too), or the sequence
+//     has no valid key at all (a fully masked row must come out uniform, see the header); the caller then recomputes the
+//     workgroup in the online form.
+template <int DT, bool DENSE, bool DIAG, bool FIXED>
+__device__ __forceinline__ bool attn_block(const int bid, char* const lds, const AttnArgs& a) {
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
   float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64] raw additive key bias
   int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);   // [2] tile has a masked / out-of-range key
+  const int Tq = a.Tq, Tk = a.Tk, kv_stride = a.kv_stride;
+  const float* const key_bias = a.key_bias;
 
   // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
   // read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
   // into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
   const int nqb = (Tq + 127) >> 7;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int xcd = bid & 7, local = bid >> 3;     // bid is wave-uniform (the callers pass it through readfirstlane)
   const int grp = (local / nqb) * 8 + xcd, qblk = local - (local / nqb) * nqb;
-  if (grp >= groups) return;
-  const int b = grp / heads, head = grp - b * heads;
+  if (grp >= a.groups) return false;
+  const int b = grp / a.heads, head = grp - b * a.heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int qrow = qblk * 128 + wave * 32 + (lane & 31);
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[query = lane&31][d = 16 i + 8 h + j]
   bf16x8 qf[4];
   {
-    const bf16_t* qp = q + ((size_t)((b + q_batch_off) / q_batch_div) * Tq + min(qrow, Tq - 1)) * q_stride + head * 64 + 8 * h;
+    const bf16_t* qp = a.q + ((size_t)((b + a.q_batch_off) / a.q_batch_div) * Tq + min(qrow, Tq - 1)) * a.q_stride + head * 64 + 8 * h;
 #pragma unroll
     for (int i = 0; i < 4; ++i) qf[i] = *(const bf16x8*)(qp + 16 * i);
   }
 
-  // ---- K/V tile staging through registers: thread handles 16-byte chunks idx = tid, tid + 256
-  const bf16_t* kbase = k + (size_t)b * Tk * kv_stride + head * 64;
-  const bf16_t* vbase = v + (size_t)b * Tk * kv_stride + head * 64;
-  uint4 kr0, kr1, vr0, vr1;
+  // ---- K/V tile staging by LDS-DMA (no staging registers): a tile is 8 + 8 pieces of 1 KiB = 8 rows x 128 B; wave w
+  // moves rows 16w..16w+15 of K and of V (2 + 2 pieces).  The DMA writes lane i's 16 bytes at piece + 16 i, i.e. row
+  // i>>3, slot i&7, so the swizzles of the two images are applied on the global side: the lane fetches the chunk that
+  // belongs in its slot.  Rows beyond Tk re-read row Tk-1 (their scores get a -inf bias).
+  const bf16_t* kbase = uniform_ptr(a.k + (size_t)b * Tk * kv_stride + head * 64);
+  const bf16_t* vbase = uniform_ptr(a.v + (size_t)b * Tk * kv_stride + head * 64);
+  const uint32_t stride2 = (uint32_t)kv_stride * 2u;
+  const int r0 = wave * 16 + (lane >> 3);                                   // piece 0 row; piece 1: + 8
+  const uint32_t ck0 = (uint32_t)((lane & 7) ^ (lane >> 4)) << 4;           // swz128: chunk ^ ((row >> 1) & 7); piece 1: ^ 4
+  const uint32_t cv = (uint32_t)((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4;   // vswz: chunk ^ (((row >> 1) & 1) << 2)
+  const uint32_t dst0 = __builtin_amdgcn_readfirstlane(lds_addr(k_img) + wave * 2048);
   float br = 0.f;
-  const int srow0 = tid >> 3, srow1 = srow0 + 32, sc = tid & 7;   // chunk idx = tid, tid + 256
-#define RR_LOAD_TILE(t)                                                                         \
+#define RR_LOAD_TILE(t, buf)                                                                    \
   {                                                                                             \
-    const size_t off0 = (size_t)min((t) * KT + srow0, Tk - 1) * kv_stride + sc * 8;             \
-    const size_t off1 = (size_t)min((t) * KT + srow1, Tk - 1) * kv_stride + sc * 8;             \
-    kr0 = *(const uint4*)(kbase + off0); kr1 = *(const uint4*)(kbase + off1);                   \
-    vr0 = *(const uint4*)(vbase + off0); vr1 = *(const uint4*)(vbase + off1);                   \
+    const uint32_t ro0 = (uint32_t)min((t) * KT + r0, Tk - 1) * stride2;                        \
+    const uint32_t ro1 = (uint32_t)min((t) * KT + r0 + 8, Tk - 1) * stride2;                    \
+    const uint32_t kd = dst0 + (buf) * TILE_BYTES;                                              \
+    glds16_so(kbase, ro0 + ck0, kd);                                                            \
+    glds16_so(kbase, ro1 + (ck0 ^ 64u), kd + 1024);                                             \
+    glds16_so(vbase, ro0 + cv, kd + 2 * TILE_BYTES);                                            \
+    glds16_so(vbase, ro1 + cv, kd + 2 * TILE_BYTES + 1024);                                     \
     if (tid < KT) {                                                                             \
       const int key = (t) * KT + tid;                                                           \
-      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;    \
+      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;            \
     }                                                                                           \
   }
 #define RR_WRITE_TILE(buf)                                                                      \
   {                                                                                             \
-    *(uint4*)(k_img + (buf) * TILE_BYTES + swz128(srow0, sc)) = kr0;                            \
-    *(uint4*)(k_img + (buf) * TILE_BYTES + swz128(srow1, sc)) = kr1;                            \
-    *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow0, sc)) = vr0;                              \
-    *(uint4*)(v_img + (buf) * TILE_BYTES + vswz(srow1, sc)) = vr1;                              \
     if (tid < KT) {                                                                             \
       b_img[(buf) * KT + tid] = br;                                                             \
       const unsigned long long any = __ballot(br != 0.f);      /* wave 0 only: tid < 64 */     \
       if (tid == 0) f_img[buf] = any != 0ull;                                                   \
     }                                                                                           \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's four pieces have landed */ \
   }
 
   f32x16 o0, o1;   // O^T[d = 32*dblk + (r&3) + 8(r>>2) + 4h][query = lane&31]
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;   // running max (log2 domain) and this lane's partial row sum
+  float m_run = -INFINITY, l_run = 0.f;   // online: running max (raw score domain); this lane's partial row sum
+  float c_ref = 0.f;                      // fixed reference: -LOG2E * the row's reference maximum, 0 until there is one
+  bool need_ref = true;                   // (all rows of a workgroup see the same keys, so this flips for all lanes at once)
 
   // diagnostic build: s_memtime marks per KV tile (read after the tile's barrier), summed per wave
   unsigned long long dg[5] = {0, 0, 0, 0, 0}, tmk[6];
 #define RR_MARK(k) { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
   const int nt = (Tk + KT - 1) / KT;
-  RR_LOAD_TILE(0)
+  const bool prio = (a.tuning & 1) != 0;
+  RR_LOAD_TILE(0, 0)
   RR_WRITE_TILE(0)
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     RR_MARK(0)
-    if (t + 1 < nt) RR_LOAD_TILE(t + 1)
+    if (t + 1 < nt) RR_LOAD_TILE(t + 1, buf ^ 1)
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
     const float* bt_ = b_img + buf * KT;
+    // wave-uniform: some key of this tile carries a bias.  DENSE: an additive bias per (query, key) on top of the
+    // per-key one (PreFLMR attention fusion, attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld],
+    // dense_ld a multiple of 64, zero padded; it only exists in the online form.
+    const bool masked = DENSE || f_img[buf] != 0;
 
     // ---- S^T tile: keys 0..31 -> s0, 32..63 -> s1; reg r <-> key (r&3) + 8(r>>2) + 4h
-    if (g_attn_prio) __builtin_amdgcn_s_setprio(2);   // MFMA sections outrank the softmax VALU of the co-resident waves
     f32x16 s0, s1;
+    auto qk = [&]() __attribute__((always_inline)) {
+      if (prio) __builtin_amdgcn_s_setprio(2);   // MFMA sections outrank the softmax VALU of the co-resident waves
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8 k0 = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
-      const bf16x8 k1 = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
-      s0 = mfma32<DT>(k0, qf[i], s0);
-      s1 = mfma32<DT>(k1, qf[i], s1);
-    }
-    if (g_attn_prio) __builtin_amdgcn_s_setprio(0);
-    RR_MARK(1)
-    // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
-    // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
-    // DENSE: an additive bias per (query, key) on top of the per-key one (PreFLMR attention fusion,
-    // attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld], dense_ld a multiple of 64, zero padded
-    const bool masked = DENSE || f_img[buf] != 0;    // wave-uniform: some key of this tile carries a bias
-    float mx;
-    if constexpr (DENSE) {
-      const float* dp = dense_bias + ((size_t)b * Tq + min(qrow, Tq - 1)) * dense_ld + t * KT + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 d0 = *(const float4*)(dp + 8 * g);
-        const float4 d1 = *(const float4*)(dp + 32 + 8 * g);
-        s0[4 * g + 0] += d0.x; s0[4 * g + 1] += d0.y; s0[4 * g + 2] += d0.z; s0[4 * g + 3] += d0.w;
-        s1[4 * g + 0] += d1.x; s1[4 * g + 1] += d1.y; s1[4 * g + 2] += d1.z; s1[4 * g + 3] += d1.w;
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8 k0 = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
+        const bf16x8 k1 = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
+        s0 = mfma32<DT>(k0, qf[i], s0);
+        s1 = mfma32<DT>(k1, qf[i], s1);
       }
-    }
-    if (masked) {
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    };
+    if (FIXED && masked) {      // the key bias is the accumulators' initial value: straight from LDS, no VALU
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
         const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
-        s0[4 * g + 0] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
-        s1[4 * g + 0] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
+        s0[4 * g + 0] = b0.x; s0[4 * g + 1] = b0.y; s0[4 * g + 2] = b0.z; s0[4 * g + 3] = b0.w;
+        s1[4 * g + 0] = b1.x; s1[4 * g + 1] = b1.y; s1[4 * g + 2] = b1.z; s1[4 * g + 3] = b1.w;
       }
+      qk();
+    } else {                    // separate copy of the MFMA chain: its first link takes the inline constant 0
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      qk();
     }
+    RR_MARK(1)
     // 32-way max; this file is built with -fno-honor-nans -mno-amdgpu-ieee (build.py) so that fmaxf lowers to bare
     // v_max3_f32 — in IEEE mode hipcc canonicalises every MFMA output first (+32 VALU per tile).  No NaN can occur:
     // inputs are finite and the only non-finite values are the -inf biases of out-of-range keys.
-    mx = fmaxf(s0[0], s1[0]);
+    auto row_max = [&]() __attribute__((always_inline)) {
+      float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);            // finite: every tile has >= 1 in-range key
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    if (masked) {
-      // (s + bias) - m is exactly 0 for a fully masked row (all entries -1e30): uniform attention, as the
-      // reference's finfo.min mask gives; a fused multiply-add form would not cancel exactly.
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      return fmaxf(mx, __shfl_xor(mx, 32, 64));
+    };
+    if constexpr (FIXED) {
+      if (__builtin_expect(need_ref, 0)) {        // first tile(s) only: take the reference from the first valid keys
+        const float mx = row_max();
+        if (mx > -1e29f) { c_ref = -mx * LOG2E; need_ref = false; }
+      }
+      // one fused multiply-add and the bare v_exp_f32 per score: a masked key is (-1e30 + q.k) -> 0 (also while there is
+      // no reference yet: c_ref = 0), a key beyond Tk is -inf -> 0
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
-        s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c_ref));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c_ref));
       }
     } else {
-      const float c = -m_new * LOG2E;
+      // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
+      // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
+      if constexpr (DENSE) {
+        const float* dp = a.dense_bias + ((size_t)b * Tq + min(qrow, Tq - 1)) * a.dense_ld + t * KT + 4 * h;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c));
-        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c));
+        for (int g = 0; g < 4; ++g) {
+          const float4 d0 = *(const float4*)(dp + 8 * g);
+          const float4 d1 = *(const float4*)(dp + 32 + 8 * g);
+          s0[4 * g + 0] += d0.x; s0[4 * g + 1] += d0.y; s0[4 * g + 2] += d0.z; s0[4 * g + 3] += d0.w;
+          s1[4 * g + 0] += d1.x; s1[4 * g + 1] += d1.y; s1[4 * g + 2] += d1.z; s1[4 * g + 3] += d1.w;
+        }
       }
+      if (masked) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
+          const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
+          s0[4 * g + 0] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
+          s1[4 * g + 0] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
+        }
+      }
+      const float m_new = fmaxf(m_run, row_max());     // finite: every tile has >= 1 in-range key
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // first tile: exp2(-inf) = 0
+      m_run = m_new;
+      if (masked) {
+        // (s + bias) - m is exactly 0 for a fully masked row (all entries -1e30): uniform attention, as the
+        // reference's finfo.min mask gives; a fused multiply-add form would not cancel exactly.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
+          s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
+        }
+      } else {
+        const float c = -m_new * LOG2E;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c));
+          s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c));
+        }
+      }
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     }
     // row sum over this lane's 32 probabilities, written as a tree so the adds pair up (v_pk_add_f32)
     typedef __attribute__((ext_vector_type(2))) float f32x2v;
@@ -205,12 +279,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       acc2 += f32x2v{s0[r], s0[r + 1]};
       acc2 += f32x2v{s1[r], s1[r + 1]};
     }
-    const float ps = acc2[0] + acc2[1];
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    l_run += acc2[0] + acc2[1];
 
-    if (g_attn_prio) __builtin_amdgcn_s_setprio(2);
+    if (prio) __builtin_amdgcn_s_setprio(2);
     RR_MARK(2)
     // ---- O^T += V^T P^T.  P fragment for k-step s of key block kb = regs 8s..8s+7 (k order:
     // element j <-> key 16 s + 8 (j>>2) + 4 h + (j&3)); V fragment gathers the same keys.
@@ -235,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         o1 = mfma32<DT>(v1, pf, o1);
       }
     }
-    if (g_attn_prio) __builtin_amdgcn_s_setprio(0);
+    if (prio) __builtin_amdgcn_s_setprio(0);
     RR_MARK(3)
     if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
     RR_MARK(4)
@@ -248,17 +319,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
   }
   if constexpr (DIAG) {
-    if (stamps && lane == 0)
-      for (int k_ = 0; k_ < 5; ++k_) stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = dg[k_];
-    if (stamps && tid == 0) stamps[((size_t)blockIdx.x * 4) * 8 + 7] = (unsigned long long)nt;
+    if (a.stamps && lane == 0)
+      for (int k_ = 0; k_ < 5; ++k_) a.stamps[((size_t)bid * 4 + wave) * 8 + k_] = dg[k_];
+    if (a.stamps && tid == 0) a.stamps[((size_t)bid * 4) * 8 + 7] = (unsigned long long)nt;
   }
 #undef RR_MARK
+#undef RR_LOAD_TILE
+#undef RR_WRITE_TILE
 
   // ---- epilogue: O = O^T / l ; lane writes 4 consecutive d per register group
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (qrow < Tq) {
-    bf16_t* op = out + ((size_t)b * Tq + qrow) * out_stride + head * 64 + 4 * h;
+    bf16_t* op = a.out + ((size_t)b * Tq + qrow) * a.out_stride + head * 64 + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       *(uint2*)(op + 8 * g) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
@@ -267,17 +340,89 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                               pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
     }
   }
+  // bound on the row sum = bound on every probability: 2^64 keeps P (bf16) times V finite in fp32; with fp16 operands P
+  // itself has to stay below 65504
+  constexpr float L_MAX = DT == 1 ? 6.0e4f : 1.8e19f;
+  if constexpr (FIXED) return __syncthreads_or(!(l_tot < L_MAX) || need_ref) != 0;
+  return false;
+}
+
+// Online form over the whole grid (DENSE bias, diagnostics, rr_set_tuning("attn_fixed_ref", 0)).
+template <int DT, bool DENSE, bool DIAG = false>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  attn_block<DT, DENSE, DIAG, false>(blockIdx.x, lds, a);
+}
+
+// Fixed-reference form over the whole grid; flags[bid] = 1 where the workgroup has to be recomputed.
+template <int DT, bool DIAG = false>
+__global__ __launch_bounds__(256, 4) void attn_fixed_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  const bool redo = attn_block<DT, false, DIAG, true>(blockIdx.x, lds, a);
+  if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
+}
+
+// Second launch of the fixed-reference schedule: workgroup i looks at flags[256 i .. 256 i + 255] (one coalesced read)
+// and recomputes the flagged workgroups of the first launch in the online form.  Normally none is flagged and this is
+// ceil(nblk / 256) workgroups that read one word each.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  __shared__ int list[256];
+  __shared__ int count;
+  if (threadIdx.x == 0) count = 0;
+  __syncthreads();
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id < a.nblk && a.flags[id]) list[atomicAdd(&count, 1)] = id;
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(count);
+  for (int j = 0; j < n; ++j) {     // workgroups are independent: the order inside the list does not matter
+    attn_block<DT, false, false, false>(__builtin_amdgcn_readfirstlane(list[j]), lds, a);
+    __syncthreads();
+  }
 }
 
 }  // namespace
 
 static unsigned long long* g_attn_stamps = nullptr;
-static int g_attn_prio_host = 1;   // rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention)
-extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on; return 0; }
+// kernel argument `tuning`: bit 0 = rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention).
+// rr_set_tuning("attn_fixed_ref"): fixed-reference schedule (two launches) for grids of at least ATTN_FIXED_MIN_BLOCKS.
+static int g_attn_prio_host = 1, g_attn_fixed_host = 1;
+constexpr long ATTN_FIXED_MIN_BLOCKS = 1024;   // below this the launch, not the softmax, is what costs
+extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; }
+extern "C" int rr_set_attn_fixed_ref(int on) { g_attn_fixed_host = on != 0; return 0; }
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
   return 0;
 }
+
+// Redo flags of the fixed-reference schedule: one word per workgroup, grow-only, one buffer per (device, stream) so that
+// launches on different streams never share one.  Written in full by the first launch and read by the second.
+namespace {
+struct FlagBuf { int* p = nullptr; long cap = 0; };
+std::mutex g_flags_mu;
+std::map<std::pair<int, hipStream_t>, FlagBuf> g_flags;
+
+hipError_t attn_flags(long nblk, hipStream_t st, int** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_flags_mu);
+  FlagBuf& f = g_flags[std::make_pair(dev, st)];
+  if (f.cap < nblk) {
+    if (f.p) {
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+      (void)hipFree(f.p);
+      f.p = nullptr; f.cap = 0;
+    }
+    const long cap = nblk + nblk / 2;
+    if ((e = hipMalloc((void**)&f.p, (size_t)cap * sizeof(int))) != hipSuccess) { f.p = nullptr; return e; }
+    f.cap = cap;
+  }
+  *out = f.p;
+  return hipSuccess;
+}
+}  // namespace
 
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
@@ -286,20 +431,29 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
+  if ((long)Tk * kv_stride * 2 >= (1L << 32)) return hipErrorInvalidValue;   // LDS-DMA: 32-bit byte offsets inside one sequence
   const long groups = (long)B * heads, nqb = (Tq + 127) / 128, nblk = ((groups + 7) / 8) * 8 * nqb;
   if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
-  dim3 grid((unsigned)nblk), block(256);
   if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
-#define RR_ATTN(DT_, DENSE_)                                                                                        \
-  hipLaunchKernelGGL((attn_fwd_kernel<DT_, DENSE_>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v, \
-                     kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, nullptr, g_attn_prio_host)
-  if (g_attn_stamps && dt == 0 && !dense_bias) {   // diagnostic timeline (tools/attn_timeline.py)
-    hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, q, q_stride, q_batch_div, q_batch_off, k, v,
-                       kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups, dense_bias, dense_ld, g_attn_stamps, g_attn_prio_host);
+  const dim3 grid((unsigned)nblk), block(256);
+  AttnArgs a{q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups,
+             dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk};
+  const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
+  if (diag) a.stamps = g_attn_stamps;
+  if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {
+    hipError_t e = attn_flags(nblk, st, &a.flags);
+    if (e != hipSuccess) return e;
+    const dim3 rgrid((unsigned)((nblk + 255) / 256));
+    if (diag) hipLaunchKernelGGL((attn_fixed_kernel<0, true>), grid, block, 0, st, a);
+    else if (dt == 0) hipLaunchKernelGGL((attn_fixed_kernel<0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_fixed_kernel<1>), grid, block, 0, st, a);
+    a.stamps = nullptr;
+    if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0>), rgrid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_redo_kernel<1>), rgrid, block, 0, st, a);
     return hipGetLastError();
   }
-  if (dt == 0) { if (dense_bias) RR_ATTN(0, true); else RR_ATTN(0, false); }
-  else { if (dense_bias) RR_ATTN(1, true); else RR_ATTN(1, false); }
-#undef RR_ATTN
+  if (diag) hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, a);
+  else if (dt == 0) { if (dense_bias) hipLaunchKernelGGL((attn_fwd_kernel<0, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((attn_fwd_kernel<0, false>), grid, block, 0, st, a); }
+  else { if (dense_bias) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, block, 0, st, a); }
   return hipGetLastError();
 }

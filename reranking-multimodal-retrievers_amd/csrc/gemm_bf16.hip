@@ -31,20 +31,6 @@ namespace {
 
 constexpr int BK = 64;
 
-// same, global address = 64-bit scalar base + 32-bit per-lane byte offset (keeps 1 VGPR per source instead of 2)
-__device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_dst_wave_base) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)
-      : "memory");
-}
-
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), i.e. waits for every global
 // store / LDS-DMA in flight — between the passes of the staged epilogue that would stall on the previous pass's
 // stores (and, in the persistent kernel, on the next tile's prefetch)

@@ -75,6 +75,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst_wave_b
       : "v"(gsrc), "s"(lds_dst_wave_base)
       : "memory");
 }
+// same, global address = 64-bit scalar base + 32-bit per-lane byte offset (keeps 1 VGPR per source instead of 2)
+__device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint32_t lds_dst_wave_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)
+      : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }

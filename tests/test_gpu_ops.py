@@ -186,6 +186,64 @@ def test_attention_online_softmax_rescale(lib):
     assert (out.float() - ref).abs().max().item() < 3e-2
 
 
+def _run_attn(lib, q, k, v, bias, heads):
+    B, Tq, H = q.shape
+    out = torch.full((B, Tq, H), float("nan"), dtype=q.dtype, device="cuda")
+    assert lib.rr_op_attention_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), H, H, bias.data_ptr() if bias is not None else 0,
+                                    B, heads, Tq, k.shape[1], 1, out.data_ptr(), H, _stream()) == 0
+    torch.cuda.synchronize()
+    return out.float()
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_attention_fixed_reference_schedule(lib, dt):
+    """The default schedule (two launches, grids >= 1024 workgroups) takes the row maximum of the first tile with a valid
+    key as a fixed softmax reference; workgroups where a row sum leaves 2^64, or that see no valid key at all, are
+    recomputed in the online form by the second launch.  Cases: (a) a later tile 20 nats above the reference stays on
+    the fixed path; (b) 230 nats above it overflows and is recomputed; (c) left padding (tile 0 fully masked) takes its
+    reference from tile 1; (d) a pair with no valid key is recomputed and comes out uniform.  All against the fp32
+    reference and against the online-only schedule of the same kernel.  dt = 1: fp16 operands, where P itself must stay
+    below 65504, so (a) is recomputed as well."""
+    t16 = torch.float16 if dt else torch.bfloat16
+    assert lib.rr_set_op_dtype(dt) == 0
+    try:
+        _fixed_reference_cases(lib, t16)
+    finally:
+        lib.rr_set_op_dtype(0)
+
+
+def _fixed_reference_cases(lib, t16):
+    B, heads, T = 48, 8, 320                          # 1 152 workgroups: the two-launch schedule starts at 1 024
+    H = heads * 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, T, H, generator=g) * 0.3
+    k = torch.randn(B, T, H, generator=g) * 0.3
+    v = torch.randn(B, T, H, generator=g)
+    k[0, 200, :64] = q[0, 17, :64] * (20.0 / float((q[0, 17, :64] ** 2).sum()))      # (a) head 0, query 17: +20
+    k[1, 300, 64:128] = q[1, 5, 64:128] * (230.0 / float((q[1, 5, 64:128] ** 2).sum()))   # (b) head 1, query 5: +230
+    bias = torch.zeros(B, T)
+    bias[2, :70] = -1e30                                                            # (c) tile 0 and 6 keys of tile 1
+    bias[0, 250:] = -1e30                                                           # ordinary tail padding on (a)
+    bias[3, :] = -1e30                                                              # (d) no valid key
+    bias[4:, 300:] = -1e30
+    q, k, v, bias = q.to(t16).cuda(), k.to(t16).cuda(), v.to(t16).cuda(), bias.cuda()
+    ref = _attn_ref(q, k, v, bias, heads)
+    got = _run_attn(lib, q, k, v, bias, heads)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-2
+    assert lib.rr_set_tuning(b"attn_fixed_ref", 0) == 0
+    try:
+        online = _run_attn(lib, q, k, v, bias, heads)
+    finally:
+        lib.rr_set_tuning(b"attn_fixed_ref", 1)
+    assert (online - ref).abs().max().item() < 3e-2
+    assert (got - online).abs().max().item() < 2e-2
+    # the recomputation IS the online form: (b) the 128-query block of head 1 that holds query 5, (d) every block of pair 3
+    assert torch.equal(got[1, :128, 64:128], online[1, :128, 64:128]) and torch.equal(got[3], online[3])
+    assert (got[3] - v[3].float().mean(0, keepdim=True)).abs().max().item() < 1e-2  # uniform attention
+    assert not torch.equal(got[4:], online[4:])                                     # ... and the rest did take the fixed path
+
+
 @pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (5, 64)])
 def test_layernorm(lib, rows, cols):
     g = torch.Generator().manual_seed(rows + cols)

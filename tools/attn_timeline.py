@@ -10,6 +10,9 @@ import rmr_amd  # noqa: E402
 from rmr_amd import _lib  # noqa: E402
 
 lib = _lib.load()
+if "--online" in sys.argv:                       # A/B: online softmax in every tile instead of the fixed-reference schedule
+    sys.argv.remove("--online")
+    assert lib.rr_set_tuning(b"attn_fixed_ref", 0) == 0
 st = torch.cuda.current_stream().cuda_stream
 B, heads, T = int(sys.argv[1]) if len(sys.argv) > 1 else 800, 12, 512
 H = heads * 64
