@@ -13,7 +13,8 @@ import glob
 import json
 import sys
 
-CLASSES = [("gemm", "gemm_kernel"), ("attention", "attn_fwd"), ("layernorm", "layernorm_kernel"),
+CLASSES = [("gemm", "gemm_kernel"), ("attention", "attn_fwd"), ("attention", "attn_fixed"), ("attention_redo", "attn_redo"),
+           ("layernorm", "layernorm_kernel"),
            ("embed", "embed_ln"), ("other", "")]
 
 
