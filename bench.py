@@ -63,6 +63,27 @@ def pmc_traffic_gb(kernel_class):
         return None
 
 
+def pmc_mfma_busy():
+    """Fraction of SIMD cycles with the MFMA pipe busy over the step's big GEMM launches, from the newest committed SQ
+    counter pass (profiles/*_sq_counters.json, tools/sq_counters.py: SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x launch
+    duration x the shader clock measured under this load), duration-weighted; and that clock in GHz."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        num = den = 0.0
+        for k, v in d["per_kernel"].items():
+            if k.startswith("gemm_kernel") and "mfma_busy" in v:
+                w = v["launches"] * v["avg_duration_ms"]
+                num += w * v["mfma_busy"]
+                den += w
+        return (num / den if den else None), d.get("shader_clock_ghz_under_load")
+    except Exception:
+        return None, None
+
+
 def host_cores():
     """CPU threads this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
     try:
@@ -209,6 +230,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_hp (16-bit MFMA GEMM, persistent half-tile LDS ring, fused epilogues; all GEMM launches of the step)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic_gb("gemm"),
+                               "mfma_busy_pmc": pmc_mfma_busy()[0], "shader_clock_ghz_pmc": pmc_mfma_busy()[1],
                                "traffic_unit": "GB per launch beyond L2 (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
                                "algorithmic_gb_per_launch": g["bytes"] / max(1, g["launches"]) / 1e9,
                                "launches": g["launches"], "avg_launch_ms": g["ms"] / max(1, g["launches"]),
