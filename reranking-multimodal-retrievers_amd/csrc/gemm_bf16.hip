@@ -1002,7 +1002,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             const int r = (F32_OUT ? 0 : wr * 64) + mt * 16 + (lane & 15);
-            char* dst = stg + r * PITCH + cn * ES;
+            // 16-bit image: rows r and r+8 of a 16-lane group would meet on the same banks (528-B pitch = 4 banks per row,
+            // 8 bytes per lane: 2-way, 8.7 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); rows with bit 3 set
+            // keep the two 8-byte halves of every 16-byte chunk swapped, the reader swaps them back
+            char* dst = stg + r * PITCH + (F32_OUT ? cn * ES : ((cn * ES) ^ (lane & 8)));
             if constexpr (F32_OUT) *(f32x4*)dst = acc[q][nt][mt];
             else *(uint2*)dst = make_uint2(pack2<DT>(acc[q][nt][mt][0], acc[q][nt][mt][1]),
                                            pack2<DT>(acc[q][nt][mt][2], acc[q][nt][mt][3]));
@@ -1041,6 +1044,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
         if (gm < M && gcol < N) {
           uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
+          if (!F32_OUT && (tid & 256)) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/32 + 16u: bit 3 of r = bit 8 of tid
           if (EPI == EPI_BIAS_RESID_F32) {
             float4 f = __builtin_bit_cast(float4, v);
             f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
