@@ -294,7 +294,7 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
  * 8 uint64 per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
  * Both are process-wide and diagnostic. */
 int rr_set_gemm_variant(int variant);
-int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (default 1) */
+int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */

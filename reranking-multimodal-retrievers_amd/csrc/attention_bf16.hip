@@ -75,7 +75,18 @@ struct AttnArgs {
   int* flags; int nblk;      // fixed-reference schedule: one word per workgroup of the grid, 1 = recompute online
 };
 
-// One workgroup's share: 128 query rows of one (pair, head), block id `bid` of the launch grid.
+// XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
+// read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
+// into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
+// bid must be wave-uniform; nqb = query blocks per (sequence, head).  False for the padding ids of the last 8-group.
+__device__ __forceinline__ bool block_map(const int bid, const int nqb, const int groups, int& grp, int& qblk) {
+  const int xcd = bid & 7, local = bid >> 3;
+  grp = (local / nqb) * 8 + xcd;
+  qblk = local - (local / nqb) * nqb;
+  return grp < groups;
+}
+
+// One workgroup's share: the 128 query rows [128 qblk, 128 qblk + 128) of (pair, head) = grp.
 //   FIXED = false: online softmax (running max, O rescaled by exp(m_old - m_new) every tile) — exact for any input.
 //   FIXED = true : the exponentials are taken against a FIXED per-row reference (the row maximum of the first tile that
 //     holds a valid key) and the key bias is the initial value of the QK^T accumulators: no running maximum, no bias add,
@@ -87,7 +98,7 @@ struct AttnArgs {
 //     has no valid key at all (a fully masked row must come out uniform, see the header); the caller then recomputes the
 //     workgroup in the online form.
 template <int DT, bool DENSE, bool DIAG, bool FIXED>
-__device__ __forceinline__ bool attn_block(const int bid, char* const lds, const AttnArgs& a) {
+__device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
   float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64] raw additive key bias
@@ -95,13 +106,6 @@ __device__ __forceinline__ bool attn_block(const int bid, char* const lds, const
   const int Tq = a.Tq, Tk = a.Tk, kv_stride = a.kv_stride;
   const float* const key_bias = a.key_bias;
 
-  // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
-  // read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
-  // into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
-  const int nqb = (Tq + 127) >> 7;
-  const int xcd = bid & 7, local = bid >> 3;     // bid is wave-uniform (the callers pass it through readfirstlane)
-  const int grp = (local / nqb) * 8 + xcd, qblk = local - (local / nqb) * nqb;
-  if (grp >= a.groups) return false;
   const int b = grp / a.heads, head = grp - b * a.heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int qrow = qblk * 128 + wave * 32 + (lane & 31);
@@ -320,8 +324,8 @@ __device__ __forceinline__ bool attn_block(const int bid, char* const lds, const
   }
   if constexpr (DIAG) {
     if (a.stamps && lane == 0)
-      for (int k_ = 0; k_ < 5; ++k_) a.stamps[((size_t)bid * 4 + wave) * 8 + k_] = dg[k_];
-    if (a.stamps && tid == 0) a.stamps[((size_t)bid * 4) * 8 + 7] = (unsigned long long)nt;
+      for (int k_ = 0; k_ < 5; ++k_) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = dg[k_];
+    if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.x * 4) * 8 + 7] = (unsigned long long)nt;
   }
 #undef RR_MARK
 #undef RR_LOAD_TILE
@@ -347,25 +351,237 @@ __device__ __forceinline__ bool attn_block(const int bid, char* const lds, const
   return false;
 }
 
+// Fixed-reference schedule with 64 query rows per wave: workgroup = 4 waves = the 256 query rows [256 qblk, 256 qblk + 256)
+// of (pair, head) = grp; a wave runs TWO independent 32-query chains (sub-blocks 0 and 1) against the same K and V
+// fragments.  What that buys (SQ counters of the 32-row form: waves 44 % parked, 35 % issue-stalled, MFMA pipe 30 % busy —
+// a wave's tile is one serial chain K reads -> MFMA -> softmax -> MFMA): the two chains give the scheduler independent
+// work to put under each other's MFMA and LDS latencies, and K/V fragments, LDS traffic and DMA pieces per query are
+// halved.  ~240 VGPRs, 2 waves per SIMD.  Same arithmetic per row as attn_block<FIXED = true>; same return value.
+template <int DT>
+__device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
+  char* const k_img = lds;
+  char* const v_img = lds + 2 * TILE_BYTES;
+  float* const b_img = (float*)(lds + 4 * TILE_BYTES);
+  int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);
+  const int Tq = a.Tq, Tk = a.Tk, kv_stride = a.kv_stride;
+  const float* const key_bias = a.key_bias;
+  const int b = grp / a.heads, head = grp - b * a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int qrow0 = qblk * 256 + wave * 64 + (lane & 31);        // sub-block 1: + 32
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const bf16_t* qp = a.q + ((size_t)((b + a.q_batch_off) / a.q_batch_div) * Tq + min(qrow0 + 32 * sb, Tq - 1)) * a.q_stride + head * 64 + 8 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qf[sb][i] = *(const bf16x8*)(qp + 16 * i);
+  }
+
+  // K/V staging by LDS-DMA, exactly as in attn_block
+  const bf16_t* kbase = uniform_ptr(a.k + (size_t)b * Tk * kv_stride + head * 64);
+  const bf16_t* vbase = uniform_ptr(a.v + (size_t)b * Tk * kv_stride + head * 64);
+  const uint32_t stride2 = (uint32_t)kv_stride * 2u;
+  const int r0 = wave * 16 + (lane >> 3);
+  const uint32_t ck0 = (uint32_t)((lane & 7) ^ (lane >> 4)) << 4;
+  const uint32_t cv = (uint32_t)((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4;
+  const uint32_t dst0 = __builtin_amdgcn_readfirstlane(lds_addr(k_img) + wave * 2048);
+  float br = 0.f;
+  auto load_tile = [&](const int t, const int buf) __attribute__((always_inline)) {
+    const uint32_t ro0 = (uint32_t)min(t * KT + r0, Tk - 1) * stride2;
+    const uint32_t ro1 = (uint32_t)min(t * KT + r0 + 8, Tk - 1) * stride2;
+    const uint32_t kd = dst0 + buf * TILE_BYTES;
+    glds16_so(kbase, ro0 + ck0, kd);
+    glds16_so(kbase, ro1 + (ck0 ^ 64u), kd + 1024);
+    glds16_so(vbase, ro0 + cv, kd + 2 * TILE_BYTES);
+    glds16_so(vbase, ro1 + cv, kd + 2 * TILE_BYTES + 1024);
+    if (tid < KT) {
+      const int key = t * KT + tid;
+      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;
+    }
+  };
+  auto write_tile = [&](const int buf) __attribute__((always_inline)) {
+    if (tid < KT) {
+      b_img[buf * KT + tid] = br;
+      const unsigned long long any = __ballot(br != 0.f);
+      if (tid == 0) f_img[buf] = any != 0ull;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  f32x16 o[2][2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[sb][0][r] = 0.f; o[sb][1][r] = 0.f; }
+  float l_run[2] = {0.f, 0.f}, c_ref[2] = {0.f, 0.f};
+  bool need_ref = true;
+  const int nt = (Tk + KT - 1) / KT;
+  const bool prio = (a.tuning & 1) != 0;
+  load_tile(0, 0);
+  write_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) load_tile(t + 1, buf ^ 1);
+    const char* kt_ = k_img + buf * TILE_BYTES;
+    const char* vt_ = v_img + buf * TILE_BYTES;
+    const float* bt_ = b_img + buf * KT;
+    const bool masked = f_img[buf] != 0;
+
+    // all eight K fragments of the tile are requested before the first MFMA and all eight V fragments before the softmax
+    // (hipcc otherwise sinks every ds_read next to its use: 4 + 4 exposed LDS latencies per tile); the scheduling fences
+    // keep the requests where they are, the waits are the compiler's counted lgkmcnt
+    bf16x8 kf[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kf[2 * i] = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
+      kf[2 * i + 1] = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s[2][2];     // [sub-block][key half]
+    auto qk = [&]() __attribute__((always_inline)) {
+      if (prio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          s[sb][0] = mfma32<DT>(kf[2 * i], qf[sb][i], s[sb][0]);
+          s[sb][1] = mfma32<DT>(kf[2 * i + 1], qf[sb][i], s[sb][1]);
+        }
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    };
+    if (masked) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
+        const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          s[sb][0][4 * g + 0] = b0.x; s[sb][0][4 * g + 1] = b0.y; s[sb][0][4 * g + 2] = b0.z; s[sb][0][4 * g + 3] = b0.w;
+          s[sb][1][4 * g + 0] = b1.x; s[sb][1][4 * g + 1] = b1.y; s[sb][1][4 * g + 2] = b1.z; s[sb][1][4 * g + 3] = b1.w;
+        }
+      }
+      qk();
+    } else {
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[sb][0][r] = 0.f; s[sb][1][r] = 0.f; }
+      qk();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 vf[8];       // [(kb, st)][d block]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int key0 = (ks >> 1) * 32 + 16 * (ks & 1) + 4 * h;
+      const int cg = 2 * ((lane >> 4) & 1);
+      vf[2 * ks] = tr_pair(vt_, key0, 0 + cg, lane);
+      vf[2 * ks + 1] = tr_pair(vt_, key0, 4 + cg, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (__builtin_expect(need_ref, 0)) {
+      bool got = false;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        float mx = fmaxf(s[sb][0][0], s[sb][1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[sb][0][r], s[sb][1][r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (mx > -1e29f) { c_ref[sb] = -mx * LOG2E; got = true; }
+      }
+      if (got) need_ref = false;       // validity is a property of the keys: both sub-blocks and all lanes agree
+    }
+    typedef __attribute__((ext_vector_type(2))) float f32x2v;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[sb][0][r] = __builtin_amdgcn_exp2f(fmaf(s[sb][0][r], LOG2E, c_ref[sb]));
+        s[sb][1][r] = __builtin_amdgcn_exp2f(fmaf(s[sb][1][r], LOG2E, c_ref[sb]));
+      }
+      f32x2v acc2 = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        acc2 += f32x2v{s[sb][0][r], s[sb][0][r + 1]};
+        acc2 += f32x2v{s[sb][1][r], s[sb][1][r + 1]};
+      }
+      l_run[sb] += acc2[0] + acc2[1];
+    }
+    if (prio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          u32x4 pw;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pw[j] = pack2<DT>(s[sb][kb][8 * st + 2 * j], s[sb][kb][8 * st + 2 * j + 1]);
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+          o[sb][0] = mfma32<DT>(vf[2 * (2 * kb + st)], pf, o[sb][0]);
+          o[sb][1] = mfma32<DT>(vf[2 * (2 * kb + st) + 1], pf, o[sb][1]);
+        }
+      }
+    }
+    if (prio) __builtin_amdgcn_s_setprio(0);
+    if (t + 1 < nt) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  constexpr float L_MAX = DT == 1 ? 6.0e4f : 1.8e19f;
+  bool bad = need_ref;
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
+    const float inv = 1.0f / l_tot;
+    bad = bad || !(l_tot < L_MAX);
+    const int qrow = qrow0 + 32 * sb;
+    if (qrow < Tq) {
+      bf16_t* op = a.out + ((size_t)b * Tq + qrow) * a.out_stride + head * 64 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *(uint2*)(op + 8 * g) = make_uint2(pack2<DT>(o[sb][0][4 * g] * inv, o[sb][0][4 * g + 1] * inv),
+                                           pack2<DT>(o[sb][0][4 * g + 2] * inv, o[sb][0][4 * g + 3] * inv));
+        *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2<DT>(o[sb][1][4 * g] * inv, o[sb][1][4 * g + 1] * inv),
+                                                pack2<DT>(o[sb][1][4 * g + 2] * inv, o[sb][1][4 * g + 3] * inv));
+      }
+    }
+  }
+  return __syncthreads_or(bad) != 0;
+}
+
 // Online form over the whole grid (DENSE bias, diagnostics, rr_set_tuning("attn_fixed_ref", 0)).
 template <int DT, bool DENSE, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
-  attn_block<DT, DENSE, DIAG, false>(blockIdx.x, lds, a);
+  int grp, qblk;
+  if (block_map(blockIdx.x, (a.Tq + 127) >> 7, a.groups, grp, qblk)) attn_block<DT, DENSE, DIAG, false>(grp, qblk, lds, a);
 }
 
 // Fixed-reference form over the whole grid; flags[bid] = 1 where the workgroup has to be recomputed.
 template <int DT, bool DIAG = false>
 __global__ __launch_bounds__(256, 4) void attn_fixed_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
-  const bool redo = attn_block<DT, false, DIAG, true>(blockIdx.x, lds, a);
+  int grp, qblk;
+  const bool redo = block_map(blockIdx.x, (a.Tq + 127) >> 7, a.groups, grp, qblk) && attn_block<DT, false, DIAG, true>(grp, qblk, lds, a);
+  if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
+}
+
+// Fixed-reference form, 256 query rows per workgroup (64 per wave); flags are per 256-row workgroup.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_fixed64_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  int grp, qblk;
+  const bool redo = block_map(blockIdx.x, (a.Tq + 255) >> 8, a.groups, grp, qblk) && attn_block64<DT>(grp, qblk, lds, a);
   if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
 }
 
 // Second launch of the fixed-reference schedule: workgroup i looks at flags[256 i .. 256 i + 255] (one coalesced read)
 // and recomputes the flagged workgroups of the first launch in the online form.  Normally none is flagged and this is
 // ceil(nblk / 256) workgroups that read one word each.
-template <int DT>
+template <int DT, int SPLIT>   // SPLIT = 128-row online workgroups per flagged workgroup of the first launch (1 or 2)
 __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
   __shared__ int list[256];
@@ -377,8 +593,13 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   __syncthreads();
   const int n = __builtin_amdgcn_readfirstlane(count);
   for (int j = 0; j < n; ++j) {     // workgroups are independent: the order inside the list does not matter
-    attn_block<DT, false, false, false>(__builtin_amdgcn_readfirstlane(list[j]), lds, a);
-    __syncthreads();
+    int grp, qblk;
+    if (!block_map(__builtin_amdgcn_readfirstlane(list[j]), (a.Tq + 128 * SPLIT - 1) / (128 * SPLIT), a.groups, grp, qblk)) continue;
+#pragma unroll
+    for (int part = 0; part < SPLIT; ++part) {
+      if ((qblk * SPLIT + part) * 128 < a.Tq) attn_block<DT, false, false, false>(grp, qblk * SPLIT + part, lds, a);
+      __syncthreads();
+    }
   }
 }
 
@@ -387,10 +608,11 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
 static unsigned long long* g_attn_stamps = nullptr;
 // kernel argument `tuning`: bit 0 = rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention).
 // rr_set_tuning("attn_fixed_ref"): fixed-reference schedule (two launches) for grids of at least ATTN_FIXED_MIN_BLOCKS.
-static int g_attn_prio_host = 1, g_attn_fixed_host = 1;
+constexpr int ATTN_FIXED_DEFAULT = 1;   // 0 online only, 1 fixed reference (32 rows per wave), 2 fixed reference (64 rows per wave)
+static int g_attn_prio_host = 1, g_attn_fixed_host = ATTN_FIXED_DEFAULT;
 constexpr long ATTN_FIXED_MIN_BLOCKS = 1024;   // below this the launch, not the softmax, is what costs
 extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; }
-extern "C" int rr_set_attn_fixed_ref(int on) { g_attn_fixed_host = on != 0; return 0; }
+extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 2) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
   return 0;
@@ -441,6 +663,18 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
   if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {
+    if (g_attn_fixed_host == 2 && !diag) {     // 64 query rows per wave: 256-row workgroups, flags per 256-row workgroup
+      const long nblk64 = ((groups + 7) / 8) * 8 * ((Tq + 255) / 256);
+      a.nblk = (int)nblk64;
+      hipError_t e = attn_flags(nblk64, st, &a.flags);
+      if (e != hipSuccess) return e;
+      const dim3 grid64((unsigned)nblk64), rgrid((unsigned)((nblk64 + 255) / 256));
+      if (dt == 0) hipLaunchKernelGGL((attn_fixed64_kernel<0>), grid64, block, 0, st, a);
+      else hipLaunchKernelGGL((attn_fixed64_kernel<1>), grid64, block, 0, st, a);
+      if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0, 2>), rgrid, block, 0, st, a);
+      else hipLaunchKernelGGL((attn_redo_kernel<1, 2>), rgrid, block, 0, st, a);
+      return hipGetLastError();
+    }
     hipError_t e = attn_flags(nblk, st, &a.flags);
     if (e != hipSuccess) return e;
     const dim3 rgrid((unsigned)((nblk + 255) / 256));
@@ -448,8 +682,8 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
     else if (dt == 0) hipLaunchKernelGGL((attn_fixed_kernel<0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((attn_fixed_kernel<1>), grid, block, 0, st, a);
     a.stamps = nullptr;
-    if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0>), rgrid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_redo_kernel<1>), rgrid, block, 0, st, a);
+    if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0, 1>), rgrid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_redo_kernel<1, 1>), rgrid, block, 0, st, a);
     return hipGetLastError();
   }
   if (diag) hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, a);

@@ -195,8 +195,9 @@ def _run_attn(lib, q, k, v, bias, heads):
     return out.float()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dt", [0, 1])
-def test_attention_fixed_reference_schedule(lib, dt):
+def test_attention_fixed_reference_schedule(lib, dt, mode):
     """The default schedule (two launches, grids >= 1024 workgroups) takes the row maximum of the first tile with a valid
     key as a fixed softmax reference; workgroups where a row sum leaves 2^64, or that see no valid key at all, are
     recomputed in the online form by the second launch.  Cases: (a) a later tile 20 nats above the reference stays on
@@ -207,12 +208,13 @@ def test_attention_fixed_reference_schedule(lib, dt):
     t16 = torch.float16 if dt else torch.bfloat16
     assert lib.rr_set_op_dtype(dt) == 0
     try:
-        _fixed_reference_cases(lib, t16)
+        _fixed_reference_cases(lib, t16, mode)
     finally:
         lib.rr_set_op_dtype(0)
 
 
-def _fixed_reference_cases(lib, t16):
+def _fixed_reference_cases(lib, t16, mode):
+    """mode 1: 32 query rows per wave (128-row workgroups); mode 2: 64 rows per wave (256-row workgroups)."""
     B, heads, T = 48, 8, 320                          # 1 152 workgroups: the two-launch schedule starts at 1 024
     H = heads * 64
     g = torch.Generator().manual_seed(11)
@@ -228,14 +230,15 @@ def _fixed_reference_cases(lib, t16):
     bias[4:, 300:] = -1e30
     q, k, v, bias = q.to(t16).cuda(), k.to(t16).cuda(), v.to(t16).cuda(), bias.cuda()
     ref = _attn_ref(q, k, v, bias, heads)
-    got = _run_attn(lib, q, k, v, bias, heads)
-    assert torch.isfinite(got).all()
-    assert (got - ref).abs().max().item() < 3e-2
-    assert lib.rr_set_tuning(b"attn_fixed_ref", 0) == 0
     try:
+        assert lib.rr_set_tuning(b"attn_fixed_ref", mode) == 0
+        got = _run_attn(lib, q, k, v, bias, heads)
+        assert lib.rr_set_tuning(b"attn_fixed_ref", 0) == 0
         online = _run_attn(lib, q, k, v, bias, heads)
     finally:
-        lib.rr_set_tuning(b"attn_fixed_ref", 1)
+        lib.rr_set_tuning(b"attn_fixed_ref", -1)          # back to the built-in default
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-2
     assert (online - ref).abs().max().item() < 3e-2
     assert (got - online).abs().max().item() < 2e-2
     # the recomputation IS the online form: (b) the 128-query block of head 1 that holds query 5, (d) every block of pair 3

@@ -13,6 +13,10 @@ lib = _lib.load()
 if "--online" in sys.argv:                       # A/B: online softmax in every tile instead of the fixed-reference schedule
     sys.argv.remove("--online")
     assert lib.rr_set_tuning(b"attn_fixed_ref", 0) == 0
+for arg in list(sys.argv):
+    if arg.startswith("--mode="):                # attn_fixed_ref value: 1 = 32 query rows per wave, 2 = 64 (no timeline marks)
+        sys.argv.remove(arg)
+        assert lib.rr_set_tuning(b"attn_fixed_ref", int(arg[7:])) == 0
 st = torch.cuda.current_stream().cuda_stream
 B, heads, T = int(sys.argv[1]) if len(sys.argv) > 1 else 800, 12, 512
 H = heads * 64
