@@ -293,6 +293,13 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
  * build, 14 = gemm_kernel_hp (persistent ring); -1 = shape heuristic (default).  rr_set_gemm_stamps: DEVICE buffer of
  * 8 uint64 per workgroup that receives s_memtime stamps (entry, first tile ready, main loop done, end), or NULL.
  * Both are process-wide and diagnostic. */
+/* e4m3 (OCP fp8) GEMM on the block-scaled matrix core (v_mfma_scale_f32_16x16x128_f8f6f4, block scales 2^0):
+ * out = epi(scale * A8[M,K] . W8[N,K]^T + bias), A8/W8 row-major e4m3 bytes, scale = the product of the two per-tensor
+ * dequantisation scales, epilogue 0 = bf16 out, 1 = bf16(erf-GELU), 2 = f32 out.  K % 128 == 0, N % 4 == 0.
+ * Building block for BASELINE configs[4] (bert-large with fp8 GEMMs); the model forward does not
+ * use it yet. */
+int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
+                   void* out, void* hip_stream);
 int rr_set_gemm_variant(int variant);
 int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librerank_mi355.so")
-SOURCES = ["rr_api.hip", "gemm_bf16.hip", "attention_bf16.hip", "elementwise.hip", "head.hip", "pair_tokenizer.cpp"]
+SOURCES = ["rr_api.hip", "gemm_bf16.hip", "gemm_fp8.hip", "attention_bf16.hip", "elementwise.hip", "head.hip", "pair_tokenizer.cpp"]
 HEADERS = [os.path.join(CSRC, "rr_common.h"), os.path.join(os.path.dirname(HERE), "include", "rerank_mi355.h"),
            os.path.join(CSRC, "unicode_tables.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -32,6 +32,7 @@ hipError_t rr_launch_gemm_ln(const bf16_t*, int, const bf16_t*, int, const float
                              const float*, const float*, void*, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
+hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, void*, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_cls_heads(const float*, int, int, int, const float*, const float*, const float*, const float*,
                                float*, float*, hipStream_t);
@@ -1368,6 +1369,14 @@ int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int
   if (epilogue < 0 || epilogue > 5 || epilogue == 4) return RR_ERR_BAD_ARG;   // 4 (residual) has its own entry point
   const int epi_map[6] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32, EPI_BIAS_TANH_BF16, -1, EPI_BIAS_QGELU_BF16};
   hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, nullptr, 0, out, N, M, N, Kd, epi_map[epilogue], g_op_dt, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
+                   void* out, void* hip_stream) {
+  if (!A8 || !W8 || !out) return RR_ERR_BAD_ARG;
+  if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, scale, out, N, M, N, K, epilogue, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
