@@ -149,7 +149,8 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     if (tid < KT) {                                                                             \
       b_img[(buf) * KT + tid] = br;                                                             \
       const unsigned long long any = __ballot(br != 0.f);      /* wave 0 only: tid < 64 */     \
-      if (tid == 0) f_img[buf] = any != 0ull;                                                   \
+      const unsigned long long valid = __ballot(br > -1e29f);                                   \
+      if (tid == 0) f_img[buf] = (any != 0ull ? 1 : 0) | (valid == 0ull ? 2 : 0);               \
     }                                                                                           \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's four pieces have landed */ \
   }
@@ -179,7 +180,13 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     // wave-uniform: some key of this tile carries a bias.  DENSE: an additive bias per (query, key) on top of the
     // per-key one (PreFLMR attention fusion, attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld],
     // dense_ld a multiple of 64, zero padded; it only exists in the online form.
-    const bool masked = DENSE || f_img[buf] != 0;
+    const int tile_flags = __builtin_amdgcn_readfirstlane(f_img[buf]);   // bit 0: some key has a bias; bit 1: no valid key
+    const bool masked = DENSE || (tile_flags & 1);
+    // Fixed-reference form only: a tile without a single valid key (tail padding) adds exactly 0 to every row sum and to
+    // O, so its QK^T, softmax and P.V are skipped (the staging of the next tile and the barrier
+    // stay).  If NO tile has a valid key the workgroup ends without a reference and is recomputed online, where every
+    // tile is processed: that is the case in which masked keys do count (uniform attention).
+    if (!(FIXED && (tile_flags & 2))) {
 
     // ---- S^T tile: keys 0..31 -> s0, 32..63 -> s1; reg r <-> key (r&3) + 8(r>>2) + 4h
     f32x16 s0, s1;
@@ -311,6 +318,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
       }
     }
     if (prio) __builtin_amdgcn_s_setprio(0);
+    }   // tile with a valid key
     RR_MARK(3)
     if (t + 1 < nt) RR_WRITE_TILE(buf ^ 1)
     RR_MARK(4)
@@ -403,7 +411,8 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     if (tid < KT) {
       b_img[buf * KT + tid] = br;
       const unsigned long long any = __ballot(br != 0.f);
-      if (tid == 0) f_img[buf] = any != 0ull;
+      const unsigned long long valid = __ballot(br > -1e29f);
+      if (tid == 0) f_img[buf] = (any != 0ull ? 1 : 0) | (valid == 0ull ? 2 : 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
@@ -426,7 +435,9 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
     const float* bt_ = b_img + buf * KT;
-    const bool masked = f_img[buf] != 0;
+    const int tile_flags = __builtin_amdgcn_readfirstlane(f_img[buf]);   // bit 0: some key has a bias; bit 1: no valid key
+    const bool masked = (tile_flags & 1) != 0;
+    if (!(tile_flags & 2)) {     // a tile without a valid key adds exactly 0: skipped (see attn_block)
 
     // all eight K fragments of the tile are requested before the first MFMA and all eight V fragments before the softmax
     // (hipcc otherwise sinks every ds_read next to its use: 4 + 4 exposed LDS latencies per tile); the scheduling fences
@@ -526,6 +537,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       }
     }
     if (prio) __builtin_amdgcn_s_setprio(0);
+    }   // tile with a valid key
     if (t + 1 < nt) write_tile(buf ^ 1);
     __syncthreads();
   }

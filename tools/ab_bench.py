@@ -15,7 +15,7 @@ arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_m
 eng = rmr_amd.RerankEngine(arch)
 eng.load_state_dict(rmr_amd.synthetic_state_dict(arch, 0, True))
 Bq, K, S = 8, 100, 512
-ids, am, tt = [t.cuda() for t in pair_batch(arch["vocab_size"], Bq, K, S)]
+ids, am, tt = [t.cuda() for t in pair_batch(arch["vocab_size"], Bq, K, S, regime=os.environ.get("RR_REGIME", "full"))]   # RR_REGIME=realistic: doc length ~ U[64, S], tail padded
 cls, pat = [t.cuda() for t in image_features(Bq, 49, 768)]
 res = {v: [] for v in vals}
 ref = None
