@@ -247,6 +247,27 @@ def _fixed_reference_cases(lib, t16, mode):
     assert not torch.equal(got[4:], online[4:])                                     # ... and the rest did take the fixed path
 
 
+def test_attention_fixed_reference_forms_are_bitwise_equal(lib):
+    """32 and 64 query rows per wave do the same arithmetic per row (same tile order, same reference, same skips)."""
+    B, heads, T = 24, 12, 512
+    H = heads * 64
+    g = torch.Generator().manual_seed(12)
+    q = (torch.randn(B, T, H, generator=g) * 0.4).bfloat16().cuda()
+    k = torch.randn(B, T, H, generator=g).bfloat16().cuda()
+    v = torch.randn(B, T, H, generator=g).bfloat16().cuda()
+    lens = torch.randint(40, T + 1, (B,), generator=g)
+    bias = torch.where(torch.arange(T)[None, :] < lens[:, None], 0.0, -1e30).float().cuda()   # tail padding: skipped tiles
+    outs = []
+    try:
+        for mode in (1, 2):
+            assert lib.rr_set_tuning(b"attn_fixed_ref", mode) == 0
+            outs.append(_run_attn(lib, q, k, v, bias, heads))
+    finally:
+        lib.rr_set_tuning(b"attn_fixed_ref", -1)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - _attn_ref(q, k, v, bias, heads)).abs().max().item() < 3e-2
+
+
 @pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (5, 64)])
 def test_layernorm(lib, rows, cols):
     g = torch.Generator().manual_seed(rows + cols)
