@@ -590,18 +590,21 @@ __global__ __launch_bounds__(256, 2) void attn_fixed64_kernel(const AttnArgs a) 
   if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
 }
 
-// Second launch of the fixed-reference schedule: workgroup i looks at flags[256 i .. 256 i + 255] (one coalesced read)
-// and recomputes the flagged workgroups of the first launch in the online form.  Normally none is flagged and this is
-// ceil(nblk / 256) workgroups that read one word each.
+// Second launch of the fixed-reference schedule: workgroup i looks at flags[16 i .. 16 i + 15] and recomputes the flagged
+// workgroups of the first launch in the online form.  Normally none is flagged and this is ceil(nblk / 16) workgroups
+// that read 64 bytes and leave (a few microseconds); if everything is flagged (e.g. fp16 operands on data whose scores
+// climb by more than 11 nats after the first tile) the recomputation is spread over as many workgroups as CUs can hold
+// and costs about one online launch, not a serial tail.
+constexpr int REDO_SPAN = 16;
 template <int DT, int SPLIT>   // SPLIT = 128-row online workgroups per flagged workgroup of the first launch (1 or 2)
 __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
-  __shared__ int list[256];
+  __shared__ int list[REDO_SPAN];
   __shared__ int count;
   if (threadIdx.x == 0) count = 0;
   __syncthreads();
-  const int id = blockIdx.x * 256 + threadIdx.x;
-  if (id < a.nblk && a.flags[id]) list[atomicAdd(&count, 1)] = id;
+  const int id = blockIdx.x * REDO_SPAN + threadIdx.x;
+  if (threadIdx.x < REDO_SPAN && id < a.nblk && a.flags[id]) list[atomicAdd(&count, 1)] = id;
   __syncthreads();
   const int n = __builtin_amdgcn_readfirstlane(count);
   for (int j = 0; j < n; ++j) {     // workgroups are independent: the order inside the list does not matter
@@ -680,7 +683,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
       a.nblk = (int)nblk64;
       hipError_t e = attn_flags(nblk64, st, &a.flags);
       if (e != hipSuccess) return e;
-      const dim3 grid64((unsigned)nblk64), rgrid((unsigned)((nblk64 + 255) / 256));
+      const dim3 grid64((unsigned)nblk64), rgrid((unsigned)((nblk64 + REDO_SPAN - 1) / REDO_SPAN));
       if (dt == 0) hipLaunchKernelGGL((attn_fixed64_kernel<0>), grid64, block, 0, st, a);
       else hipLaunchKernelGGL((attn_fixed64_kernel<1>), grid64, block, 0, st, a);
       if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0, 2>), rgrid, block, 0, st, a);
@@ -689,7 +692,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
     }
     hipError_t e = attn_flags(nblk, st, &a.flags);
     if (e != hipSuccess) return e;
-    const dim3 rgrid((unsigned)((nblk + 255) / 256));
+    const dim3 rgrid((unsigned)((nblk + REDO_SPAN - 1) / REDO_SPAN));
     if (diag) hipLaunchKernelGGL((attn_fixed_kernel<0, true>), grid, block, 0, st, a);
     else if (dt == 0) hipLaunchKernelGGL((attn_fixed_kernel<0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((attn_fixed_kernel<1>), grid, block, 0, st, a);

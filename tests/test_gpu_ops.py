@@ -247,6 +247,25 @@ def _fixed_reference_cases(lib, t16, mode):
     assert not torch.equal(got[4:], online[4:])                                     # ... and the rest did take the fixed path
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_every_workgroup_recomputed(lib, mode):
+    """No valid key anywhere: the first launch flags every workgroup and the second one recomputes all of them."""
+    B, heads, T = 48, 8, 384                                # 48 * 8 * 3 = 1 152 workgroups of 128 rows
+    H = heads * 64
+    g = torch.Generator().manual_seed(13)
+    q = torch.randn(B, T, H, generator=g).bfloat16().cuda()
+    k = torch.randn(B, T, H, generator=g).bfloat16().cuda()
+    v = torch.randn(B, T, H, generator=g).bfloat16().cuda()
+    bias = torch.full((B, T), -1e30).cuda()
+    try:
+        assert lib.rr_set_tuning(b"attn_fixed_ref", mode) == 0
+        got = _run_attn(lib, q, k, v, bias, heads)
+    finally:
+        lib.rr_set_tuning(b"attn_fixed_ref", -1)
+    want = v.float().mean(1, keepdim=True).expand(B, T, H)
+    assert torch.isfinite(got).all() and (got - want).abs().max().item() < 1e-2
+
+
 def test_attention_fixed_reference_forms_are_bitwise_equal(lib):
     """32 and 64 query rows per wave do the same arithmetic per row (same tile order, same reference, same skips)."""
     B, heads, T = 24, 12, 512

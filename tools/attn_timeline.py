@@ -32,9 +32,11 @@ def run(bias):
                                     bias, B, heads, T, T, 1, out.data_ptr(), H, st)
 
 
-for name, bias in (("no mask", 0), ("masked path", kb.data_ptr())):
+for name, bias in (("no mask", 0), ("masked path", kb.data_ptr()), ("no valid key: every workgroup recomputed online", kb.data_ptr())):
     if bias:
         kb[:, 400:] = -1e30
+    if name.startswith("no valid"):
+        kb[:] = -1e30
     for _ in range(2):
         assert run(bias) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
