@@ -90,13 +90,12 @@ __device__ __forceinline__ bool block_map(const int bid, const int nqb, const in
 //   FIXED = false: online softmax (running max, O rescaled by exp(m_old - m_new) every tile) — exact for any input.
 //   FIXED = true : the exponentials are taken against a FIXED per-row reference (the row maximum of the first tile that
 //     holds a valid key) and the key bias is the initial value of the QK^T accumulators: no running maximum, no bias add,
-//     no O rescale — 138 VALU instructions per tile instead of ~205 on a kernel that is VALU-issue-bound (DESIGN.md
-//     §7.3), and 146 VGPRs.  softmax is shift-invariant and fp32 keeps its relative precision at any exponent, so the
-//     result differs from the online form in rounding only, as long as nothing overflows.  Returns true when it did not
-//     hold: a row sum left 2^64 (6e4 with fp16 operands; a later score far above the reference — inf and NaN fail the
-//     test too), or the sequence
-//     has no valid key at all (a fully masked row must come out uniform, see the header); the caller then recomputes the
-//     workgroup in the online form.
+//     no O rescale — 138 VALU instructions per tile instead of ~205, and with LDS-DMA staging 128 VGPRs, i.e. 4 waves
+//     per SIMD.  softmax is shift-invariant and fp32 keeps its relative precision at any exponent, so
+//     the result differs from the online form in rounding only, as long as nothing overflows.  Tiles without a valid
+//     key are skipped.  Returns true when the schedule did not hold: a row sum left 2^64 (6e4 with fp16 operands; a
+//     later score far above the reference — inf and NaN fail the test too), or the sequence has no valid key at all (a
+//     fully masked row must come out uniform, see the header); the caller then recomputes the workgroup online.
 template <int DT, bool DENSE, bool DIAG, bool FIXED>
 __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
   char* const k_img = lds;                       // [2][8 KiB]
