@@ -300,6 +300,11 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
  * use it yet. */
 int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
                    void* out, void* hip_stream);
+/* Per-tensor e4m3 quantisation for rr_op_gemm_fp8: out[i] = e4m3(clamp(x[i] / scale, +-448)), round to nearest even;
+ * x holds n (a multiple of 8) f32 values (x_is_f32 != 0) or bf16 values.  rr_op_amax: *out_dev (device float) = max |x|
+ * (exact and order-independent), from which the caller derives scale = amax / 448. */
+int rr_op_quantize_fp8(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream);
+int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream);
 int rr_set_gemm_variant(int variant);
 int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */

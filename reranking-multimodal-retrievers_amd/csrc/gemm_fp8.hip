@@ -131,7 +131,78 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_f8(const uint8_t* __r
   }
 }
 
+// ---- per-tensor quantisation: y = e4m3(clamp(x / scale, +-448)), round to nearest even (v_cvt_pk_fp8_f32, OCP on gfx950)
+template <bool F32_IN>
+__global__ void quant_e4m3_kernel(const void* __restrict__ xv, float inv_scale, uint8_t* __restrict__ y, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float f[8];
+  if constexpr (F32_IN) {
+    const float4 a = ((const float4*)xv)[2 * i], b = ((const float4*)xv)[2 * i + 1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    const uint4 u = ((const uint4*)xv)[i];
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * inv_scale, -448.0f, 448.0f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  ((uint2*)y)[i] = make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+
+// max |x| of a tensor: non-negative floats order like their bit patterns, so an integer atomicMax is exact and
+// independent of the order of arrival.  *out must be zeroed by the caller (rr_launch_amax does).
+template <bool F32_IN>
+__global__ void amax_kernel(const void* __restrict__ xv, size_t n8, unsigned int* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    if constexpr (F32_IN) {
+      const float4 a = ((const float4*)xv)[2 * i], b = ((const float4*)xv)[2 * i + 1];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+    } else {
+      const uint4 u = ((const uint4*)xv)[i];
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        m = fmaxf(m, fmaxf(fabsf(__uint_as_float(w[j] << 16)), fabsf(__uint_as_float(w[j] & 0xffff0000u))));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 }  // namespace
+
+// x: n elements (n % 8 == 0) of f32 or of the 16-bit type bf16; y: n e4m3 bytes = e4m3(clamp(x / scale, +-448)).
+hipError_t rr_launch_quant_e4m3(const void* x, int x_is_f32, float scale, uint8_t* y, size_t n, hipStream_t st) {
+  if ((n & 7) || !(scale > 0.f)) return hipErrorInvalidValue;
+  const size_t n8 = n >> 3;
+  if (n8 == 0) return hipSuccess;
+  const dim3 grid((unsigned)((n8 + 255) / 256)), block(256);
+  if (x_is_f32) hipLaunchKernelGGL((quant_e4m3_kernel<true>), grid, block, 0, st, x, 1.0f / scale, y, n8);
+  else hipLaunchKernelGGL((quant_e4m3_kernel<false>), grid, block, 0, st, x, 1.0f / scale, y, n8);
+  return hipGetLastError();
+}
+
+// *out (device float) = max |x|.
+hipError_t rr_launch_amax(const void* x, int x_is_f32, size_t n, float* out, hipStream_t st) {
+  if (n & 7) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  const size_t n8 = n >> 3;
+  if (n8 == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)(n8 + 255) / 256 < 2048u ? (unsigned)((n8 + 255) / 256) : 2048u;
+  if (x_is_f32) hipLaunchKernelGGL((amax_kernel<true>), dim3(blocks), dim3(256), 0, st, x, n8, (unsigned int*)out);
+  else hipLaunchKernelGGL((amax_kernel<false>), dim3(blocks), dim3(256), 0, st, x, n8, (unsigned int*)out);
+  return hipGetLastError();
+}
 
 // A8 [M,Kd] e4m3 bytes (row stride lda bytes), W8 [N,Kd] e4m3 (row stride ldw), bias [N] f32 or null, scale = sa * sw
 // (per-tensor dequantisation), C: bf16 (epilogue 0, 1) or f32 (2), row stride ldc elements.  Kd % 128 == 0, N % 4 == 0.

@@ -33,6 +33,8 @@ hipError_t rr_launch_gemm_ln(const bf16_t*, int, const bf16_t*, int, const float
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
 hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, void*, int, int, int, int, int, hipStream_t);
+hipError_t rr_launch_quant_e4m3(const void*, int, float, uint8_t*, size_t, hipStream_t);
+hipError_t rr_launch_amax(const void*, int, size_t, float*, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_cls_heads(const float*, int, int, int, const float*, const float*, const float*, const float*,
                                float*, float*, hipStream_t);
@@ -1377,6 +1379,18 @@ int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, floa
   if (!A8 || !W8 || !out) return RR_ERR_BAD_ARG;
   if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, scale, out, N, M, N, K, epilogue, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_quantize_fp8(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
+  if (!x || !out) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_quant_e4m3(x, x_is_f32, scale, out, n, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream) {
+  if (!x || !out_dev) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_amax(x, x_is_f32, n, out_dev, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 

@@ -59,3 +59,50 @@ def test_gemm_fp8_rejects_bad_shapes(lib):
     assert lib.rr_op_gemm_fp8(x.data_ptr(), x.data_ptr(), 0, 1.0, 256, 256, 192, 2, out.data_ptr(), _stream()) != 0   # K % 128
     assert lib.rr_op_gemm_fp8(x.data_ptr(), x.data_ptr(), 0, 1.0, 256, 254, 128, 2, out.data_ptr(), _stream()) != 0   # N % 4
     assert lib.rr_op_gemm_fp8(x.data_ptr(), x.data_ptr(), 0, 1.0, 256, 256, 128, 7, out.data_ptr(), _stream()) != 0   # epilogue
+
+
+@pytest.mark.parametrize("src", ["f32", "bf16"])
+def test_quantize_and_amax_match_torch(lib, src):
+    g = torch.Generator().manual_seed(5)
+    n = 8 * 12345
+    x = torch.randn(n, generator=g) * 3.0
+    x[::97] *= 40.0                                             # values beyond the e4m3 range after scaling: saturate
+    x[5] = 0.0
+    xd = x.cuda() if src == "f32" else x.bfloat16().cuda()
+    xs = xd.float().cpu()                                       # what the device actually sees
+    amax = torch.zeros(1, device="cuda")
+    assert lib.rr_op_amax(xd.data_ptr(), int(src == "f32"), n, amax.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    assert amax.item() == xs.abs().max().item()
+    scale = 0.05                                                # deliberately too small: |x| / scale exceeds 448 for some
+    out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert lib.rr_op_quantize_fp8(xd.data_ptr(), int(src == "f32"), scale, out.data_ptr(), n, _stream()) == 0
+    torch.cuda.synchronize()
+    want = (xs * (1.0 / scale)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)   # same 1/scale multiply as the device
+    got = out.cpu()
+    diff = got != want
+    assert not diff.any(), f"{int(diff.sum())} of {n} bytes differ, first at {int(diff.nonzero()[0])}"
+
+
+def test_device_quantised_gemm_end_to_end(lib):
+    """amax -> scale -> quantise on the device -> e4m3 GEMM, against the fp32 product of the unquantised operands:
+    the error is the e4m3 quantisation noise (2^-4 relative per element, averaging over K)."""
+    M, N, K = 512, 768, 1024
+    g = torch.Generator().manual_seed(6)
+    a = (torch.randn(M, K, generator=g) * 0.8).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).cuda()
+    amax = torch.zeros(2, device="cuda")
+    assert lib.rr_op_amax(a.data_ptr(), 0, a.numel(), amax.data_ptr(), _stream()) == 0
+    assert lib.rr_op_amax(w.data_ptr(), 1, w.numel(), amax.data_ptr() + 4, _stream()) == 0
+    sa, sw = (amax.cpu() / 448.0).tolist()
+    a8 = torch.empty(M, K, dtype=torch.uint8, device="cuda")
+    w8 = torch.empty(N, K, dtype=torch.uint8, device="cuda")
+    assert lib.rr_op_quantize_fp8(a.data_ptr(), 0, sa, a8.data_ptr(), a.numel(), _stream()) == 0
+    assert lib.rr_op_quantize_fp8(w.data_ptr(), 1, sw, w8.data_ptr(), w.numel(), _stream()) == 0
+    out = torch.empty(M, N, device="cuda")
+    assert lib.rr_op_gemm_fp8(a8.data_ptr(), w8.data_ptr(), 0, sa * sw, M, N, K, 2, out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = a.float() @ w.T
+    rel = ((out - ref).norm() / ref.norm()).item()
+    print(f"[fp8 gemm, device-quantised] relative Frobenius error vs the 16-bit-operand product: {rel:.3e}")
+    assert rel < 0.05
