@@ -142,6 +142,15 @@ const char* rr_required_weight_name(rr_handle h, int i);
 /* Bytes of grow-only device workspace rr_forward would hold for this shape. */
 int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len);
 
+/* rr_reserve: allocate once, outside the forward, everything a forward over at most n_pairs pairs of n_queries queries
+ * would otherwise grow on first use (workspace, the attention kernels' redo flags for `hip_stream`, and with
+ * with_fusion != 0 the attention-fusion bias).  len_a = seq_len for full-context models, Lq for interaction models;
+ * len_b = Lc (interaction models only).  After rr_reserve no forward of that or a smaller shape allocates, frees or
+ * synchronises, which makes the forward capturable into a hipGraph; without it the first forward of a larger shape
+ * grows the buffers (synchronising the stream) and a forward under stream capture that would have to grow fails with
+ * RR_ERR_BAD_ARG.  The module's constructor-time analogue in the reference: none (PyTorch's caching allocator). */
+int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream);
+
 /* rr_forward: one pass of the hot path over N = Bq*K (query,candidate) pairs.
  *   input_ids, attention_mask, token_type_ids : DEVICE int64 [N,S] row-major, query-major pair order
  *       (prepare_full_context_inputs, utils.py:129-167).  attention_mask masks keys in the text

@@ -397,6 +397,36 @@ def fusion_adjacency(preflmr_scores: Tensor, ql: int, P: int, S: int, fusion_mul
     return torch.cat([torch.cat([ul, ur], 2), torch.cat([bl, br], 2)], 1) * fusion_multiplier   # :309-315
 
 
+def joint_sequence(query_input_ids: Tensor, query_attention_mask: Tensor, context_input_ids: Tensor,
+                   context_attention_mask: Tensor, K: int) -> Tuple[Tensor, Tensor]:
+    """rerank_model.py:190-224: the query ids repeated K times, followed by the context ids cut to [2, 2 - ql)."""
+    ql = query_input_ids.shape[1]
+    q_ids = query_input_ids.repeat_interleave(K, 0)
+    q_am = query_attention_mask.repeat_interleave(K, 0)
+    lt, rt = 2, 2 - ql                                                                      # :204-205
+    return (torch.cat([q_ids, context_input_ids[:, lt:rt]], 1),                             # :207-215
+            torch.cat([q_am, context_attention_mask[:, lt:rt]], 1))                         # :216-224
+
+
+def reorder_query_image_context(xin: Tensor, mask01: Tensor, ql: int, S: int) -> Tuple[Tensor, Tensor]:
+    """rerank_model.py:241-274: the vision tokens join the mask as ones, then inputs and mask are re-ordered from
+    [query | context | image] to [query | image | context]."""
+    N, P = xin.shape[0], xin.shape[1] - S
+    m = torch.cat([mask01, torch.ones(N, P)], 1)                                            # :245-254
+    xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)                             # :257-264
+    m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)                                     # :267-274
+    return xin, m
+
+
+def interaction_fusion_adjacency(preflmr_scores: Tensor, fusion_multiplier: float) -> Tensor:
+    """interaction_rerank_model.py:131-142: scores [N, Lc, Lq] -> additive bias over the tokens [query | context]."""
+    N, Lc, Lq = preflmr_scores.shape
+    ur = torch.softmax(preflmr_scores.permute(0, 2, 1), dim=-1)
+    bl = torch.softmax(preflmr_scores, dim=-1)
+    return torch.cat([torch.cat([torch.zeros(N, Lq, Lq), ur], 2), torch.cat([bl, torch.zeros(N, Lc, Lc)], 2)], 1) \
+        * fusion_multiplier
+
+
 def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_ids: Tensor, query_attention_mask: Tensor,
                          context_input_ids: Tensor, context_attention_mask: Tensor, K: int, image_cls: Tensor,
                          image_patches: Tensor, instruction_token_id: Optional[int] = None, mm=None,
@@ -408,11 +438,8 @@ def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_id
     assert N == context_input_ids.shape[0]                                                  # :188
     S = context_input_ids.shape[1]
     assert S == cfg.max_pos                                                                 # :202
-    q_ids = query_input_ids.repeat_interleave(K, 0)
-    q_am = query_attention_mask.repeat_interleave(K, 0)
-    lt, rt = 2, 2 - ql                                                                      # :204-205
-    joint_ids = torch.cat([q_ids, context_input_ids[:, lt:rt]], 1)                          # :207-215
-    joint_am = torch.cat([q_am, context_attention_mask[:, lt:rt]], 1)
+    joint_ids, joint_am = joint_sequence(query_input_ids, query_attention_mask, context_input_ids,
+                                         context_attention_mask, K)
     taps = {} if want_taps else None
     img_c = image_cls.repeat_interleave(K, 0)
     img_p = image_patches.repeat_interleave(K, 0)
@@ -434,9 +461,7 @@ def rerank_model_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_input_id
     Q = F.normalize(torch.cat([text, prefix, t], 1), p=2, dim=2)
     xin = linear(Q, w, "cross_encoder_input_mapping", mm)                                   # :237-239
     P = xin.shape[1] - S
-    m = torch.cat([mask, torch.ones(N, P)], 1)                                              # :245-254
-    xin = torch.cat((xin[:, :ql], xin[:, S:], xin[:, ql:S]), 1)                            # :257-264
-    m = torch.cat((m[:, :ql], m[:, S:], m[:, ql:S]), 1)                                     # :267-274
+    xin, m = reorder_query_image_context(xin, mask, ql, S)                                  # :245-274
     adj = None if preflmr_scores is None else fusion_adjacency(preflmr_scores, ql, P, S, fusion_multiplier)
     l1, l2 = cross_encoder(cfg, w, xin, m, adj, mm, taps)                                   # :321-325
     logits, _ = prepare_logits_labels(cfg.loss_fn, l1, l2, Bq, K - 1, None)                 # :327
@@ -490,11 +515,7 @@ def interaction_forward(cfg: OracleConfig, w: Dict[str, Tensor], query_li: Tenso
     if preflmr_scores is not None:                                                                  # :131-142
         if mores:
             raise NotImplementedError("Attention adj is not implemented for MORES")
-        Lq, Lc = query_li.shape[1], context_li.shape[1]
-        ur = torch.softmax(preflmr_scores.permute(0, 2, 1), dim=-1)
-        bl = torch.softmax(preflmr_scores, dim=-1)
-        adj = torch.cat([torch.cat([torch.zeros(N, Lq, Lq), ur], 2), torch.cat([bl, torch.zeros(N, Lc, Lc)], 2)], 1) \
-            * fusion_multiplier
+        adj = interaction_fusion_adjacency(preflmr_scores, fusion_multiplier)
     if mores:                                                                                       # :147-156
         h = linear(q, w, "cross_encoder_input_mapping", mm)
         doc = linear(context_li.to(torch.float32), w, "cross_encoder_input_mapping", mm)
@@ -724,8 +745,8 @@ def weight_spec(cfg: OracleConfig, vision: bool) -> List[Tuple[str, Tuple[int, .
     return s
 
 
-def make_weights(cfg: OracleConfig, seed: int = 0, vision: bool = False, hf_init: bool = False
-                 ) -> Dict[str, Tensor]:
+def make_weights(cfg: OracleConfig, seed: int = 0, vision: bool = False, hf_init: bool = False,
+                 gain: float = 1.0) -> Dict[str, Tensor]:
     """Seeded synthetic weights.  `hf_init=True`: HF init (matrices/embeddings
     N(0,0.02), LN gamma 1 / beta 0, biases 0 — modeling_flmr.py:199-214) as the bench
     uses; default (tests): same matrices but non-trivial biases/gamma/beta so that
@@ -735,7 +756,10 @@ def make_weights(cfg: OracleConfig, seed: int = 0, vision: bool = False, hf_init
     for idx, (name, shape, kind) in enumerate(weight_spec(cfg, vision)):
         g = torch.Generator().manual_seed(seed * 1000003 + idx)
         if kind in ("w", "e"):
-            t = torch.randn(shape, generator=g) * 0.02
+            # `gain` > 1 widens the Linear matrices only (not the embeddings): a 0.02-std random network is nearly linear
+            # and maps every candidate of a query to almost the same CLS state (logit spread 0.007 at bert-base), so
+            # rankings are noise; at gain 2.5 attention is peaked and the spread is ~0.2 (tests/golden c3_sep)
+            t = torch.randn(shape, generator=g) * (0.02 * (gain if kind == "w" else 1.0))
         elif kind == "g":
             t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
         else:

@@ -646,6 +646,9 @@ hipError_t attn_flags(long nblk, hipStream_t st, int** out) {
   std::lock_guard<std::mutex> lock(g_flags_mu);
   FlagBuf& f = g_flags[std::make_pair(dev, st)];
   if (f.cap < nblk) {
+    // growth synchronises and frees: not while the stream is being captured (rr_reserve sizes the buffer beforehand)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported;
     if (f.p) {
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
       (void)hipFree(f.p);
@@ -659,6 +662,15 @@ hipError_t attn_flags(long nblk, hipStream_t st, int** out) {
   return hipSuccess;
 }
 }  // namespace
+
+// Pre-size the redo-flag buffer of (current device, st) for an attention launch of B sequences x heads x Tq query rows,
+// so that the launch path never allocates (rr_reserve; required before capturing a forward into a hipGraph).
+hipError_t rr_attention_reserve(int B, int heads, int Tq, hipStream_t st) {
+  if (B <= 0 || heads <= 0 || Tq <= 0) return hipErrorInvalidValue;
+  const long groups = (long)B * heads, nblk = ((groups + 7) / 8) * 8 * ((Tq + 127) / 128);
+  int* p = nullptr;
+  return attn_flags(nblk, st, &p);
+}
 
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,

@@ -25,7 +25,9 @@
 //     activation row-panel run on one XCD so the panel is fetched from HBM once per XCD L2.
 #include "rr_common.h"
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -161,27 +163,31 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
 
   // per-piece source = scalar base (A or W, advanced by k0) + a 32-bit per-lane byte offset that lives in ONE VGPR for
   // the whole kernel: nothing rewrites an address register behind an LDS-DMA that may still be waiting to issue
+  // The 64-bit part of the address (tile origin) is a scalar; the 32-bit per-lane offset only spans the tile's own rows
+  // (< 256 rows x row pitch), so operands of any size are addressed correctly (no 4 GiB limit on A or W).
   uint32_t a_off[PA], w_off[PW];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int r = (wave * PA + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    a_off[i] = (uint32_t)(((size_t)min(m0 + r, M - 1) * lda + c * 8) * 2);
+    a_off[i] = (uint32_t)(((size_t)min(r, M - 1 - m0) * lda + c * 8) * 2);
   }
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
     const int r = (wave * PW + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    w_off[i] = (uint32_t)(((size_t)min(n0 + r, N - 1) * ldw + c * 8) * 2);
+    w_off[i] = (uint32_t)(((size_t)min(r, N - 1 - n0) * ldw + c * 8) * 2);
   }
+  const bf16_t* const a_tile = A + (size_t)m0 * lda;
+  const bf16_t* const w_tile = W + (size_t)n0 * ldw;
   const uint32_t lds_base = lds_addr(lds);
   auto stage = [&](int buf, int k0) {
     const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * PA * 1024);
     const uint32_t w_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + A_BYTES + wave * PW * 1024);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16_so(A + k0, a_off[i], a_dst + i * 1024);
+    for (int i = 0; i < PA; ++i) glds16_so(a_tile + k0, a_off[i], a_dst + i * 1024);
 #pragma unroll
-    for (int i = 0; i < PW; ++i) glds16_so(W + k0, w_off[i], w_dst + i * 1024);
+    for (int i = 0; i < PW; ++i) glds16_so(w_tile + k0, w_off[i], w_dst + i * 1024);
   };
 
   f32x4 acc[NT][MT];   // lane holds m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg
@@ -358,24 +364,27 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   const int wr = wave >> 2, wc = wave & 3;
 
   // ---- DMA sources: half-tile j in {0:A0, 1:B0, 2:B1, 3:A1}; this wave moves pieces 2*wave, 2*wave+1 (8 rows each).
-  // 32-bit byte offsets from the (scalar) A / W base: operands are < 4 GiB.
+  // 32-bit byte offsets from the scalar origin of THIS tile's rows (a_tile / w_tile): they span at most 256 row
+  // pitches, so A and W may be of any size.
   uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + (lane >> 3);          // row inside the half-tile
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    so_a0[i] = (uint32_t)(((size_t)min(m0 + r, M - 1) * lda + c * 8) * 2);
-    so_a1[i] = (uint32_t)(((size_t)min(m0 + 128 + r, M - 1) * lda + c * 8) * 2);
-    so_b0[i] = (uint32_t)(((size_t)min(n0 + r, N - 1) * ldw + c * 8) * 2);
-    so_b1[i] = (uint32_t)(((size_t)min(n0 + 128 + r, N - 1) * ldw + c * 8) * 2);
+    so_a0[i] = (uint32_t)(((size_t)min(r, M - 1 - m0) * lda + c * 8) * 2);
+    so_a1[i] = (uint32_t)(((size_t)min(128 + r, M - 1 - m0) * lda + c * 8) * 2);
+    so_b0[i] = (uint32_t)(((size_t)min(r, N - 1 - n0) * ldw + c * 8) * 2);
+    so_b1[i] = (uint32_t)(((size_t)min(128 + r, N - 1 - n0) * ldw + c * 8) * 2);
   }
+  const bf16_t* const a_tile = A + (size_t)m0 * lda;
+  const bf16_t* const w_tile = W + (size_t)n0 * ldw;
   const uint32_t lds_base = lds_addr(lds);
   const int nk = Kd / BK, H = 4 * nk;
   // half-tile (t, J): slot = parity (t&1) * 4 + J; J is a compile-time constant at every call site
 #define RR_DMA(t_, J)                                                                                             \
   {                                                                                                               \
     const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
-    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(A + (size_t)(t_) * BK) : (const void*)(W + (size_t)(t_) * BK); \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)(t_) * BK) : (const void*)(w_tile + (size_t)(t_) * BK); \
     const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
     glds16_so(sb_, so_[0], dst_);                                                                                 \
     glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
@@ -735,17 +744,21 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   const int wr = wave >> 2, wc = wave & 3;
 
   // ---- DMA sources: half-tile j in {0:A0, 1:B0, 2:B1, 3:A1}; this wave moves pieces 2*wave, 2*wave+1 (8 rows each).
-  // 32-bit byte offsets from the (scalar) A / W base: operands are < 4 GiB.
+  // 32-bit byte offsets from the scalar origin of the CURRENT tile's rows (a_tile / w_tile, re-based per output tile):
+  // they span at most 256 row pitches, so A and W may be of any size.
   uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
+  const bf16_t *a_tile, *w_tile;
 #define RR_SETUP_SRC(m0_, n0_)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
     const int r = (wave * 2 + i) * 8 + (lane >> 3);          /* row inside the half-tile */             \
     const int c = (lane & 7) ^ ((r >> 1) & 7);                                                          \
-    so_a0[i] = (uint32_t)(((size_t)min((m0_) + r, M - 1) * lda + c * 8) * 2);                           \
-    so_a1[i] = (uint32_t)(((size_t)min((m0_) + 128 + r, M - 1) * lda + c * 8) * 2);                     \
-    so_b0[i] = (uint32_t)(((size_t)min((n0_) + r, N - 1) * ldw + c * 8) * 2);                           \
-    so_b1[i] = (uint32_t)(((size_t)min((n0_) + 128 + r, N - 1) * ldw + c * 8) * 2);                     \
-  }
+    so_a0[i] = (uint32_t)(((size_t)min(r, M - 1 - (m0_)) * lda + c * 8) * 2);                           \
+    so_a1[i] = (uint32_t)(((size_t)min(128 + r, M - 1 - (m0_)) * lda + c * 8) * 2);                     \
+    so_b0[i] = (uint32_t)(((size_t)min(r, N - 1 - (n0_)) * ldw + c * 8) * 2);                           \
+    so_b1[i] = (uint32_t)(((size_t)min(128 + r, N - 1 - (n0_)) * ldw + c * 8) * 2);                     \
+  }                                                                                                     \
+  a_tile = A + (size_t)(m0_) * lda;                                                                     \
+  w_tile = W + (size_t)(n0_) * ldw;
   RR_SETUP_SRC(m0, n0)
   const uint32_t lds_base = lds_addr(lds);
   const int nk = Kd / BK, H = 4 * nk;
@@ -753,7 +766,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #define RR_DMA(t_, J)                                                                                             \
   {                                                                                                               \
     const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
-    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(A + (size_t)(t_) * BK) : (const void*)(W + (size_t)(t_) * BK); \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)(t_) * BK) : (const void*)(w_tile + (size_t)(t_) * BK); \
     const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
     glds16_so(sb_, so_[0], dst_);                                                                                 \
     glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
@@ -1070,7 +1083,32 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
-int g_variant = -1;                      // tuning override (rr_set_gemm_variant); -1: shape heuristic
+std::atomic<int> g_variant{-1};          // tuning override (rr_set_gemm_variant / RR_GEMM_VARIANT); -1: shape heuristic
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember per device ordinal where
+// it has been set (several rr_handles on different devices may live in one process).  Devices >= 64: set every launch.
+inline hipError_t ensure_lds_attr(const void* kern, int lds_bytes, std::atomic<unsigned long long>& mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release);
+  return hipSuccess;
+}
+// CUs of the current device (rounded down to a multiple of 8), cached per device ordinal
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c) return c; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  const int n = prop.multiProcessorCount & ~7;
+  if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 int g_persistent = 1;                     // rr_set_tuning("persistent_gemm"): 1 = variant 14 for large problems, 0 = variant 12
@@ -1081,13 +1119,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   if (N & 7) return hipErrorInvalidValue;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidValue;
-    n_cu = prop.multiProcessorCount & ~7;
-  }
+  const int n_cu = device_cus();
   if (n_cu < 8) return hipErrorInvalidValue;
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
@@ -1095,11 +1127,10 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
     auto kern = gemm_kernel_hp<E, DT>;                                                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    static std::atomic<unsigned long long> attr_mask{0};     /* one bit per device ordinal: the attribute is per device */ \
+    {                                                                                                         \
+      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
       if (e != hipSuccess) return e;                                                                          \
-      attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
                        tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);                                   \
@@ -1131,17 +1162,16 @@ hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const fl
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
     auto kern = gemm_kernel_h<E, LDS_EPI, DT>;                                                                \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    static std::atomic<unsigned long long> attr_mask{0};     /* one bit per device ordinal: the attribute is per device */ \
+    {                                                                                                         \
+      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
       if (e != hipSuccess) return e;                                                                          \
-      attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
                        tiles_n, nwg, stamps, ln, nwg > 512 ? g_stagger : 0);                                                             \
     break;                                                                                                    \
   }
-  if (g_variant == 13) {   // diagnostic timeline build (tools/bench_gemm.py --timeline): bf16, bias -> 16-bit only
+  if (g_variant.load() == 13) {   // diagnostic timeline build (tools/bench_gemm.py --timeline): bf16, bias -> 16-bit only
     if (!LDS_EPI || DT != 0 || epilogue != EPI_BIAS_BF16) return hipErrorInvalidValue;
     auto kern = gemm_kernel_h<EPI_BIAS_BF16, true, 0, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1180,11 +1210,10 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
     auto kern = gemm_kernel_s<BM, BN, WM, WN, STAGES, E, LDS_EPI, DT>;                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    static std::atomic<unsigned long long> attr_mask{0};     /* one bit per device ordinal: the attribute is per device */ \
+    {                                                                                                         \
+      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
       if (e != hipSuccess) return e;                                                                          \
-      attr_set = true;                                                                                        \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
                        tiles_n, nwg, stamps, (BM == 256 && BN == 256 && nwg > 512) ? g_stagger : 0, ln);     \
@@ -1209,7 +1238,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
   if (v < -1 || v > 14) return -1;
-  g_variant = v;
+  g_variant.store(v);
   return 0;
 }
 extern "C" int rr_set_gemm_persistent(int on) {
@@ -1248,13 +1277,12 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
   if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;
-  static bool env_read = false;
-  if (!env_read) {
+  static std::once_flag env_once;
+  std::call_once(env_once, [] {
     const char* e = getenv("RR_GEMM_VARIANT");
-    if (e && g_variant < 0) g_variant = atoi(e);
-    env_read = true;
-  }
-  int v = g_variant;
+    if (e && g_variant.load() < 0) g_variant.store(atoi(e));
+  });
+  int v = g_variant.load();
   if (v < 0) {
     // big problems: 256x256 tiles, persistent half-tile LDS ring (variant HP) with the LDS-staged coalesced epilogue; small ones:
     // 128x128 so the grid still fills 256 CUs (measured with tools/bench_gemm.py --stamps, profiles/).

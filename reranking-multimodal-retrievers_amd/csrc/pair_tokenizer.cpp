@@ -20,6 +20,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -141,10 +142,19 @@ class WorkerPool {
       job_ = &fn; want_ = n - 1; done_ = 0; ++gen_;
     }
     cv_job_.notify_all();
-    fn();
-    std::unique_lock<std::mutex> g(m_);
-    cv_done_.wait(g, [&] { return done_ == want_; });
-    job_ = nullptr;
+    // An exception in any participant (the caller's share included) is kept, every worker is still waited for — they
+    // reference the caller's stack through `fn` — and the first exception is rethrown to the caller afterwards, where the
+    // extern "C" entry point turns it into a status code.  Nothing ever unwinds out of a worker thread (std::terminate).
+    try { fn(); } catch (...) { std::lock_guard<std::mutex> g(m_); if (!err_) err_ = std::current_exception(); }
+    std::exception_ptr err;
+    {
+      std::unique_lock<std::mutex> g(m_);
+      cv_done_.wait(g, [&] { return done_ == want_; });
+      job_ = nullptr;
+      err = err_;
+      err_ = nullptr;
+    }
+    if (err) std::rethrow_exception(err);
   }
 
  private:
@@ -164,8 +174,10 @@ class WorkerPool {
         if (id < want_) job = job_;
       }
       if (job) {
-        (*job)();
+        std::exception_ptr e;
+        try { (*job)(); } catch (...) { e = std::current_exception(); }
         std::lock_guard<std::mutex> g(m_);
+        if (e && !err_) err_ = e;
         ++done_;
         cv_done_.notify_all();
       }
@@ -178,6 +190,7 @@ class WorkerPool {
   unsigned long long gen_ = 0;
   int want_ = 0, done_ = 0;
   bool stop_ = false;
+  std::exception_ptr err_;
 };
 
 }  // namespace

@@ -11,7 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -40,6 +42,7 @@ hipError_t rr_launch_cls_heads(const float*, int, int, int, const float*, const 
                                float*, float*, hipStream_t);
 hipError_t rr_launch_head(const float*, const float*, const float*, int, int, int, float, int, float*, int32_t*,
                           float*, float*, float*, hipStream_t);
+hipError_t rr_attention_reserve(int B, int heads, int Tq, hipStream_t st);
 
 namespace {
 
@@ -159,14 +162,30 @@ struct rr_model {
 
 namespace {
 
-int fail(rr_model* m, int code, const char* fmt, ...) {
+int fail(rr_model* m, int code, const char* fmt, ...) noexcept {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (m) m->err = buf;
+  if (m) { try { m->err = buf; } catch (...) {} }
   return code;
+}
+
+// No C++ exception crosses the C ABI: every extern "C" entry point runs its body through guarded().  bad_alloc (host
+// vectors/maps/strings of the weight staging, the event pool, ...) -> RR_ERR_OOM, anything else -> RR_ERR_BAD_ARG with the
+// message kept for rr_last_error().
+template <class R = int, class F>
+R guarded(rr_model* m, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return (R)fail(m, RR_ERR_OOM, "out of host memory");
+  } catch (const std::exception& e) {
+    return (R)fail(m, RR_ERR_BAD_ARG, "internal error: %s", e.what());
+  } catch (...) {
+    return (R)fail(m, RR_ERR_BAD_ARG, "internal error (unknown exception)");
+  }
 }
 
 #define RR_HIP(m, call)                                                                        \
@@ -527,8 +546,19 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   return (b.off + 255) & ~(size_t)255;
 }
 
+// Growth outside rr_reserve synchronises the stream and frees the old block: legal on a plain stream, not while the
+// stream is being captured into a graph (and it would invalidate pointers baked into earlier captures) -> refused there.
+int capture_guard(rr_model* m, hipStream_t st, const char* what) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return fail(m, RR_ERR_BAD_ARG, "%s would have to grow during stream capture; call rr_reserve for the largest shape "
+                                   "before capturing", what);
+  return RR_OK;
+}
+
 int ensure_ws(rr_model* m, size_t bytes, hipStream_t st) {
   if (bytes <= m->ws_cap) return RR_OK;
+  RR_TRY(capture_guard(m, st, "the workspace"));
   if (m->ws) {
     RR_HIP(m, hipStreamSynchronize(st));
     RR_HIP(m, hipFree(m->ws));
@@ -604,6 +634,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
 // grow-only buffer of the attention-fusion bias [n][T][ld]
 int ensure_adj(rr_model* m, size_t bytes, hipStream_t st) {
   if (bytes <= m->adj_cap) return RR_OK;
+  RR_TRY(capture_guard(m, st, "the attention-fusion bias buffer"));
   if (m->adj) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->adj)); m->adj = nullptr; m->adj_cap = 0; }
   RR_HIP(m, hipMalloc((void**)&m->adj, bytes));
   m->adj_cap = bytes;
@@ -711,7 +742,7 @@ const char* rr_status_string(int s) {
 
 static thread_local std::string g_create_err;
 
-int rr_create(const rr_config* cfg, rr_handle* out) {
+static int rr_create_impl(const rr_config* cfg, rr_handle* out) {
   if (!cfg || !out) return RR_ERR_BAD_ARG;
   *out = nullptr;
   if (cfg->abi_version != RR_ABI_VERSION) { g_create_err = "abi_version mismatch"; return RR_ERR_BAD_ARG; }
@@ -764,7 +795,7 @@ int rr_create(const rr_config* cfg, rr_handle* out) {
 
 const char* rr_last_error(rr_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int rr_destroy(rr_handle h) {
+static int rr_destroy_impl(rr_handle h) {
   if (!h) return RR_ERR_BAD_ARG;
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
@@ -783,7 +814,7 @@ const char* rr_required_weight_name(rr_handle h, int i) {
   return h->required_order[i].c_str();
 }
 
-int rr_load_weight(rr_handle h, const char* name, const void* data, int dtype, int ndim, const int64_t* shape,
+static int rr_load_weight_impl(rr_handle h, const char* name, const void* data, int dtype, int ndim, const int64_t* shape,
                    int* known) {
   if (!h || !name || !data || ndim < 0 || (ndim > 0 && !shape)) return fail(h, RR_ERR_BAD_ARG, "rr_load_weight: null argument");
   if (h->finalized) return fail(h, RR_ERR_BAD_ARG, "rr_load_weight after rr_finalize_weights");
@@ -811,7 +842,7 @@ int rr_load_weight(rr_handle h, const char* name, const void* data, int dtype, i
   return RR_OK;
 }
 
-int rr_finalize_weights(rr_handle h) {
+static int rr_finalize_weights_impl(rr_handle h) {
   if (!h) return RR_ERR_BAD_ARG;
   if (h->finalized) return RR_OK;
   for (const auto& n : h->required_order)
@@ -888,13 +919,41 @@ int rr_finalize_weights(rr_handle h) {
   return RR_OK;
 }
 
-int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len) {
+static int64_t rr_workspace_bytes_impl(rr_handle h, int n_pairs, int seq_len) {
   if (!h || n_pairs <= 0 || seq_len <= 0) return RR_ERR_BAD_ARG;
   Work w;
   return (int64_t)layout(h->cfg, n_pairs, n_pairs, seq_len, h->cfg.has_vision != 0, nullptr, &w);
 }
 
-int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_cls_out, float* image_patches_out,
+/* rr_reserve: allocate, once and outside the forward, everything a forward over at most n_pairs pairs of n_queries
+ * queries would otherwise grow on first use: the workspace, the attention redo flags of `hip_stream`, and (with_fusion)
+ * the attention-fusion bias.  len_a = seq_len (full-context models) or Lq (interaction), len_b = Lc (interaction only). */
+static int rr_reserve_impl(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
+  if (!h) return RR_ERR_BAD_ARG;
+  rr_model* m = h;
+  const rr_config& c = m->cfg;
+  if (n_pairs <= 0 || n_queries <= 0 || len_a <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_reserve: n_pairs=%d n_queries=%d len=%d", n_pairs, n_queries, len_a);
+  hipStream_t st = (hipStream_t)hip_stream;
+  RR_HIP(m, hipSetDevice(c.device));
+  Work w{};
+  size_t need;
+  int T;
+  if (c.model_kind == RR_MODEL_FULL_CONTEXT) {
+    need = layout(c, n_pairs, n_queries, len_a, c.has_vision != 0, nullptr, &w);
+    T = len_a + (c.has_vision ? c.prefix_len + c.n_patches : 0);
+    RR_HIP(m, rr_attention_reserve(n_pairs, c.heads, len_a, st));
+  } else {
+    if (len_b <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_reserve: interaction models need len_b = Lc");
+    need = layout_interaction(c, n_pairs, n_queries, len_a, len_b, nullptr, &w);
+    T = len_a + len_b;
+  }
+  RR_HIP(m, rr_attention_reserve(n_pairs, c.ce_heads, T, st));
+  RR_TRY(ensure_ws(m, need, st));
+  if (with_fusion) RR_TRY(ensure_adj(m, (size_t)n_pairs * T * ((T + 63) / 64 * 64) * sizeof(float), st));
+  return RR_OK;
+}
+
+static int rr_encode_image_impl(rr_handle h, const float* pixel_values, int B, float* image_cls_out, float* image_patches_out,
                     void* hip_stream) {
   if (!h || !pixel_values || !image_cls_out || !image_patches_out) return fail(h, RR_ERR_BAD_ARG, "rr_encode_image: null argument");
   rr_model* m = h;
@@ -940,7 +999,7 @@ int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_
   return RR_OK;
 }
 
-int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,
+static int rr_head_impl(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K,
             float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
   if (!h || !logits) return fail(h, RR_ERR_BAD_ARG, "rr_head: null argument");
   if (Bq <= 0 || K <= 0) return fail(h, RR_ERR_BAD_SHAPE, "rr_head: Bq=%d K=%d", Bq, K);
@@ -1136,7 +1195,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
                    loss_out, scores_out, order_out, joint != 0);
 }
 
-int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+static int rr_forward_impl(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
                const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels,
                int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
                float* scores_out, int32_t* order_out, void* hip_stream) {
@@ -1145,7 +1204,7 @@ int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_m
                       -1);
 }
 
-int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+static int rr_forward_joint_impl(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
                      const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len,
                      int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out,
                      float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
@@ -1154,7 +1213,7 @@ int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t*
                       query_len, (long long)instruction_token_id);
 }
 
-int rr_forward_joint_fusion(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
+static int rr_forward_joint_fusion_impl(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
                             const float* image_cls, const float* image_patches, const float* preflmr_scores,
                             float fusion_multiplier, int Bq, int K, int S, int query_len, int64_t instruction_token_id,
                             int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
@@ -1275,7 +1334,7 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
                    order_out);
 }
 
-int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+static int rr_forward_interaction_impl(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
                            const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels,
                            int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out,
                            float* scores_out, int32_t* order_out, void* hip_stream) {
@@ -1283,7 +1342,7 @@ int rr_forward_interaction(rr_handle h, const float* query_li, const float* cont
                              logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, nullptr, 1.0f);
 }
 
-int rr_forward_interaction_fusion(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
+static int rr_forward_interaction_fusion_impl(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
                                   const float* context_mask, const float* preflmr_scores, float fusion_multiplier, int Bq,
                                   int K, int Lq, int Lc, const float* labels, int pair_begin, int pair_end,
                                   float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
@@ -1294,7 +1353,7 @@ int rr_forward_interaction_fusion(rr_handle h, const float* query_li, const floa
                              fusion_multiplier);
 }
 
-int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems) {
+static int64_t rr_debug_read_impl(rr_handle h, const char* name, float* host_out, int64_t max_elems) {
   if (!h || !name || !host_out) return RR_ERR_BAD_ARG;
   if (hipSetDevice(h->cfg.device) != hipSuccess) return RR_ERR_HIP;
   if (hipStreamSynchronize(h->last_stream) != hipSuccess) return fail(h, RR_ERR_HIP, "stream sync failed");
@@ -1332,7 +1391,7 @@ int rr_set_profiling(rr_handle h, int on) {
   return RR_OK;
 }
 
-int rr_get_profile(rr_handle h, rr_profile* out, int reset) {
+static int rr_get_profile_impl(rr_handle h, rr_profile* out, int reset) {
   if (!h || !out) return RR_ERR_BAD_ARG;
   RR_HIP(h, hipSetDevice(h->cfg.device));
   for (size_t i = 0; i < h->ev_used; ++i) {
@@ -1365,7 +1424,7 @@ int rr_set_op_dtype(int dt) {
   return RR_OK;
 }
 
-int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue,
+static int rr_op_gemm_bf16_impl(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue,
                     void* out, void* hip_stream) {
   if (!A || !W || !out) return RR_ERR_BAD_ARG;
   if (epilogue < 0 || epilogue > 5 || epilogue == 4) return RR_ERR_BAD_ARG;   // 4 (residual) has its own entry point
@@ -1374,7 +1433,7 @@ int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
+static int rr_op_gemm_fp8_impl(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
                    void* out, void* hip_stream) {
   if (!A8 || !W8 || !out) return RR_ERR_BAD_ARG;
   if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
@@ -1382,26 +1441,26 @@ int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, floa
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_quantize_fp8(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
+static int rr_op_quantize_fp8_impl(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
   if (!x || !out) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_quant_e4m3(x, x_is_f32, scale, out, n, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream) {
+static int rr_op_amax_impl(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream) {
   if (!x || !out_dev) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_amax(x, x_is_f32, n, out_dev, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N,
+static int rr_op_gemm_resid_f32_impl(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N,
                          int Kd, float* out, void* hip_stream) {
   if (!A || !W || !out || !resid) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_gemm(A, Kd, W, Kd, bias, resid, N, out, N, M, N, Kd, EPI_BIAS_RESID_F32, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
+static int rr_op_attention_bf16_impl(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride,
                          const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out,
                          int out_stride, void* hip_stream) {
   if (!q || !k || !v || !out) return RR_ERR_BAD_ARG;
@@ -1410,24 +1469,99 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
-int rr_op_gemm_ln_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* x, const float* stats,
+static int rr_op_gemm_ln_resid_f32_impl(const uint16_t* A, const uint16_t* W, const float* bias, const float* x, const float* stats,
                             const float* gamma, const float* beta, int M, int N, int Kd, float* out, void* hip_stream) {
   if (!A || !W || !out || !x || !stats || !gamma || !beta) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_gemm_ln(A, Kd, W, Kd, bias, x, N, stats, gamma, beta, out, N, M, N, Kd, EPI_BIAS_RESID_F32, g_op_dt,
                                    (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
-int rr_op_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+static int rr_op_layernorm_stats_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                           float* out_f32, uint16_t* out_bf16, float* stats, void* hip_stream) {
   if (!x || !gamma || !beta || !out_bf16 || !stats) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_layernorm_stats(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, stats, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
-int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+static int rr_op_layernorm_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream) {
   if (!x || !gamma || !beta || (!out_f32 && !out_bf16)) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_layernorm(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+
+
+// ---- the exported entry points: bodies above, run through guarded() so that no C++ exception crosses the ABI
+int rr_create(const rr_config* cfg, rr_handle* out) {
+  return guarded(nullptr, [&]() -> int { return rr_create_impl(cfg, out); });
+}
+int rr_destroy(rr_handle h) {
+  return guarded(h, [&]() -> int { return rr_destroy_impl(h); });
+}
+int rr_load_weight(rr_handle h, const char* name, const void* data, int dtype, int ndim, const int64_t* shape, int* known) {
+  return guarded(h, [&]() -> int { return rr_load_weight_impl(h, name, data, dtype, ndim, shape, known); });
+}
+int rr_finalize_weights(rr_handle h) {
+  return guarded(h, [&]() -> int { return rr_finalize_weights_impl(h); });
+}
+int rr_encode_image(rr_handle h, const float* pixel_values, int B, float* image_cls_out, float* image_patches_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_encode_image_impl(h, pixel_values, B, image_cls_out, image_patches_out, hip_stream); });
+}
+int rr_head(rr_handle h, const float* logits, const float* logits2, const float* labels, int Bq, int K, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_head_impl(h, logits, logits2, labels, Bq, K, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_impl(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, Bq, K, S, labels, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask, const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len, int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_joint_impl(h, joint_input_ids, joint_attention_mask, image_cls, image_patches, Bq, K, S, query_len, instruction_token_id, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward_joint_fusion(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask, const float* image_cls, const float* image_patches, const float* preflmr_scores, float fusion_multiplier, int Bq, int K, int S, int query_len, int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_joint_fusion_impl(h, joint_input_ids, joint_attention_mask, image_cls, image_patches, preflmr_scores, fusion_multiplier, Bq, K, S, query_len, instruction_token_id, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward_interaction(rr_handle h, const float* query_li, const float* context_li, const float* query_mask, const float* context_mask, int Bq, int K, int Lq, int Lc, const float* labels, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_interaction_impl(h, query_li, context_li, query_mask, context_mask, Bq, K, Lq, Lc, labels, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward_interaction_fusion(rr_handle h, const float* query_li, const float* context_li, const float* query_mask, const float* context_mask, const float* preflmr_scores, float fusion_multiplier, int Bq, int K, int Lq, int Lc, const float* labels, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_interaction_fusion_impl(h, query_li, context_li, query_mask, context_mask, preflmr_scores, fusion_multiplier, Bq, K, Lq, Lc, labels, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_get_profile(rr_handle h, rr_profile* out, int reset) {
+  return guarded(h, [&]() -> int { return rr_get_profile_impl(h, out, reset); });
+}
+int rr_op_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_bf16_impl(A, W, bias, M, N, Kd, epilogue, out, hip_stream); });
+}
+int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue, void* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_impl(A8, W8, bias, scale, M, N, K, epilogue, out, hip_stream); });
+}
+int rr_op_quantize_fp8(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_quantize_fp8_impl(x, x_is_f32, scale, out, n, hip_stream); });
+}
+int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_amax_impl(x, x_is_f32, n, out_dev, hip_stream); });
+}
+int rr_op_gemm_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N, int Kd, float* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_resid_f32_impl(A, W, bias, resid, M, N, Kd, out, hip_stream); });
+}
+int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int q_stride, int kv_stride, const float* key_bias, int B, int heads, int Tq, int Tk, int q_batch_div, uint16_t* out, int out_stride, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_attention_bf16_impl(q, k, v, q_stride, kv_stride, key_bias, B, heads, Tq, Tk, q_batch_div, out, out_stride, hip_stream); });
+}
+int rr_op_gemm_ln_resid_f32(const uint16_t* A, const uint16_t* W, const float* bias, const float* x, const float* stats, const float* gamma, const float* beta, int M, int N, int Kd, float* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_ln_resid_f32_impl(A, W, bias, x, stats, gamma, beta, M, N, Kd, out, hip_stream); });
+}
+int rr_op_layernorm_stats(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, float* out_f32, uint16_t* out_bf16, float* stats, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_layernorm_stats_impl(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, stats, hip_stream); });
+}
+int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, float* out_f32, uint16_t* out_bf16, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_layernorm_impl(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, hip_stream); });
+}
+int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_reserve_impl(h, n_pairs, n_queries, len_a, len_b, with_fusion, hip_stream); });
+}
+int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len) {
+  return guarded<int64_t>(h, [&]() -> int64_t { return rr_workspace_bytes_impl(h, n_pairs, seq_len); });
+}
+int64_t rr_debug_read(rr_handle h, const char* name, float* host_out, int64_t max_elems) {
+  return guarded<int64_t>(h, [&]() -> int64_t { return rr_debug_read_impl(h, name, host_out, max_elems); });
 }
 
 }  // extern "C"

@@ -436,6 +436,12 @@ class RerankEngine:
     def workspace_bytes(self, n_pairs: int, S: int) -> int:
         return int(self.lib.rr_workspace_bytes(self.h, n_pairs, S))
 
+    def reserve(self, n_pairs: int, n_queries: int, len_a: int, len_b: int = 0, with_fusion: bool = False):
+        """Allocate everything a forward of at most this shape needs (rr_reserve) on the current stream: afterwards the
+        forward neither allocates nor synchronises (a precondition for capturing it into a hipGraph)."""
+        L.check(self.lib.rr_reserve(self.h, int(n_pairs), int(n_queries), int(len_a), int(len_b), int(with_fusion),
+                                    torch.cuda.current_stream(self.device).cuda_stream), self.h, "rr_reserve")
+
 
 class _FrozenStub(torch.nn.Module):
     """Placeholder for `context_vision_encoder`: the executor only iterates its `named_parameters()` to

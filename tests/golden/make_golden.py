@@ -375,13 +375,176 @@ def run_case(name, outdir):
     )
 
 
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bf16-autocast goldens: the reference's ACTUAL arithmetic (`precision: 'bf16'` = Lightning bf16-mixed,
+# configs/Rerank/OKVQA/Encoder/monoPreFLMR-B_pointwise.jsonnet:186,233): fp32 parameters, torch.autocast(bfloat16) around
+# the forward.  This container has no GPU, so the CUDA autocast policy is emulated on the CPU: torch.autocast("cpu",
+# bfloat16) already runs linear / matmul / bmm in bf16 (fp32 accumulate, bf16 result); what the CPU policy lacks is the
+# CUDA policy's fp32 list, of which this path touches softmax and layer_norm — both are forced to fp32 here, as
+# `torch/csrc/autograd/autocast_mode.cpp` (CUDA section: softmax, layer_norm, ... under KERNEL(..., fp32)) does on a GPU.
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def cuda_autocast_emulation():
+    import torch.nn.functional as F
+    real_softmax, real_ln = F.softmax, F.layer_norm
+
+    def softmax32(input, dim=None, _stacklevel=3, dtype=None):
+        with torch.autocast("cpu", enabled=False):
+            return real_softmax(input.float(), dim=dim)
+
+    def ln32(input, normalized_shape, weight=None, bias=None, eps=1e-5):
+        with torch.autocast("cpu", enabled=False):
+            return real_ln(input.float(), normalized_shape, None if weight is None else weight.float(),
+                           None if bias is None else bias.float(), eps)
+
+    F.softmax, F.layer_norm = softmax32, ln32
+    keep_t = torch.softmax
+    torch.softmax = lambda x, dim=-1, dtype=None: softmax32(x, dim)
+    try:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            yield
+    finally:
+        F.softmax, F.layer_norm, torch.softmax = real_softmax, real_ln, keep_t
+
+
+def _labels_for(loss, n):
+    if loss == "negative_sampling":
+        return None
+    rng = np.random.Generator(np.random.PCG64(5))
+    return [float(x) for x in (rng.random(n) < 0.3)]
+
+
+def run_autocast_goldens(outdir, names):
+    """logits / loss of the stock-HF assembly under the emulated CUDA bf16 autocast, for the cases of CASES and
+    INTERACTION_CASES named in `names` -> autocast.npz (keys `<case>.logits`, `<case>.loss`).  The gate of the GPU tests
+    for the bf16 mode is |device - fp32| <= max(1e-3, |autocast - fp32|) per case."""
+    path = os.path.join(outdir, "autocast.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in names:
+        if name in CASES:
+            kw, Bq, K, S, vision, regime, loss = CASES[name]
+            cfg = O.OracleConfig(**kw)
+            cfg.loss_fn = loss
+            w = O.make_weights(cfg, seed=0, vision=vision)
+            ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=2022, regime=regime)
+            img = O.make_image_feats(cfg, Bq) if vision else (None, None)
+            labels = _labels_for(loss, Bq * K)
+            hf = HFAssembly(cfg, w, vision)
+            _, ref, _, _ = hf.forward(ids, am, tt, Bq, K, img[0], img[1], labels)
+            with cuda_autocast_emulation():
+                l_ac, lg_ac, _, _ = hf.forward(ids, am, tt, Bq, K, img[0], img[1], labels)
+        else:
+            kw, Bq, K, Lq, Lc, mores, loss = INTERACTION_CASES[name]
+            cfg = O.OracleConfig(**kw)
+            cfg.loss_fn = loss
+            w = O.make_interaction_weights(cfg, mores, seed=0)
+            q, c, qm, cm = O.make_interaction_inputs(cfg, Bq, K, Lq, Lc)
+            labels = _labels_for(loss, Bq * K)
+            hf = HFInteraction(cfg, w, mores)
+            _, ref = hf.forward(q, c, qm, cm, K, labels)
+            with cuda_autocast_emulation():
+                l_ac, lg_ac = hf.forward(q, c, qm, cm, K, labels)
+        lg = lg_ac.float().reshape(-1)
+        d = (lg - ref.reshape(-1)).abs().max().item()
+        print(f"[autocast {name}] |autocast - fp32| max {d:.3e}  (logits dtype under autocast: {lg_ac.dtype})")
+        out[f"{name}.logits"] = lg.numpy()
+        out[f"{name}.loss"] = np.array(float(l_ac), dtype=np.float32)
+        out[f"{name}.drift_vs_fp32"] = np.array(d, dtype=np.float32)
+    np.savez_compressed(path, **out)
+
+
+def _hf_logits_chunked(hf, ids, am, tt, K, img, chunk=100):
+    """Pointwise logits of ONE query's K candidates in chunks (pairs are independent: rerank_model.py:541-555)."""
+    outs = []
+    for b in range(0, K, chunk):
+        e = min(K, b + chunk)
+        _, lg, _, _ = hf.forward(ids[b:e], am[b:e], tt[b:e], 1, e - b, img[0], img[1], None)
+        outs.append(lg.float().reshape(-1))
+    return torch.cat(outs)
+
+
+FULLSIZE = {
+    # name: (cfg kwargs, vision, S, pool per query)        BASELINE configs[2] / configs[4] / monoPreFLMR-L shapes
+    "c3_full": (dict(), True, 512, 100),
+    "c3_sep": (dict(), True, 512, 300),
+    "c5_full": (dict(hidden=1024, layers=24, heads=16, intermediate=4096, ce_hidden=1024, ce_heads=16,
+                     ce_intermediate=4096), False, 512, 200),
+    "l_shape": (dict(vision_hidden=1024, n_patches=256, ce_max_pos=900), True, 512, 8),   # monoPreFLMR-L_pointwise.jsonnet:117
+}
+
+
+def run_fullsize_case(name, outdir):
+    """Full-size goldens (fp32 stock-HF logits + the bf16-autocast logits of the same lists).
+    c3_full: K = 100, S = 512, P = 81 (BASELINE configs[2]), one query, the list as drawn.
+    c3_sep: the same shape with the Linear matrices widened (make_weights gain 2.5: a 0.02-std random network scores all
+      candidates of a query within +-0.02, i.e. at the bf16 noise level; widened, the logit spread is ~0.2) and, for TWO
+      queries, a list of 100 chosen from a pool of 300 seeded candidates so that the fp32 logits leave a gap of >= 0.08
+      between rank 5 and rank 6 (pairs are scored independently: choosing the list changes no logit).  The Recall@5 /
+      top-5 parity test is then a statement about the kernels, not about ties: query 0's only positive sits at fp32 rank
+      5, query 1's at rank 6, so Recall@5 must come out 1 and 0.
+    c5_full: bert-large text-only, K = 200, S = 512 (BASELINE configs[4] shape) as drawn.
+    l_shape: monoPreFLMR-L geometry (ViT-L/14 features: 1024-d, 256 patches, P = 288, T = 800, position table 900), K = 8."""
+    kw, vision, S, pool = FULLSIZE[name]
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = "BCE"
+    gain = 2.5 if name == "c3_sep" else 1.0
+    w = O.make_weights(cfg, seed=0, vision=vision, gain=gain)
+    hf = HFAssembly(cfg, w, vision)
+    nq = 2 if name == "c3_sep" else 1
+    rec = dict(cfg_json=np.array(repr(kw)), S=S, vision=vision, pool=pool, nq=nq, gain=np.array(gain, dtype=np.float32))
+    for qi in range(nq):
+        seed = 2022 + 31 * qi
+        ids, am, tt = O.make_pair_batch(cfg, 1, pool, S, seed=seed, regime="realistic")
+        # one query: the query span (tokens 1..32) is the same text for all its candidates
+        ids[:, 1:33] = ids[0, 1:33]
+        img = O.make_image_feats(cfg, 1, seed=seed) if vision else (None, None)
+        import time
+        t0 = time.time()
+        fp32 = _hf_logits_chunked(hf, ids, am, tt, pool, img)
+        t1 = time.time()
+        with cuda_autocast_emulation():
+            ac = _hf_logits_chunked(hf, ids, am, tt, pool, img)
+        print(f"[{name} q{qi}] pool of {pool}: fp32 {t1 - t0:.0f} s, autocast {time.time() - t1:.0f} s; "
+              f"|autocast - fp32| max {(ac - fp32).abs().max():.3e}; logit std {fp32.std():.3f}")
+        rec[f"q{qi}.seed"] = seed
+        rec[f"q{qi}.ids_checksum"] = np.array(int(ids.sum()))
+        rec[f"q{qi}.pool_logits"] = fp32.numpy()
+        rec[f"q{qi}.pool_logits_autocast"] = ac.numpy()
+        if name == "c3_sep":
+            order = sorted(range(pool), key=lambda i: -fp32[i].item())
+            top5 = order[:5]
+            j = 5
+            while j < pool and fp32[order[4]] - fp32[order[j]] < 0.08:
+                j += 1
+            rest = order[j:j + 95]
+            assert len(rest) == 95, f"pool too small for a 0.08 gap (j={j})"
+            rng = np.random.Generator(np.random.PCG64(99 + qi))
+            sel = np.array(top5 + rest)
+            rng.shuffle(sel)
+            rec[f"q{qi}.selected"] = sel.astype(np.int32)                       # pool indices, list order
+            pos_rank = 5 if qi == 0 else 6                                      # 1-based fp32 rank of the only positive
+            pos_pool = (top5 + rest)[pos_rank - 1]
+            rec[f"q{qi}.positive_list_index"] = np.array(int(np.where(sel == pos_pool)[0][0]))
+            rec[f"q{qi}.gap_5_6"] = np.array(float(fp32[order[4]] - fp32[rest[0]]), dtype=np.float32)
+            print(f"   selected list: rank-5/6 gap {rec[f'q{qi}.gap_5_6']:.4f}, positive at fp32 rank {pos_rank}")
+    np.savez_compressed(os.path.join(outdir, f"{name}.npz"), **rec)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default=",".join(list(CASES) + list(INTERACTION_CASES) + ["rm_tiny", "rm_fuse_tiny"] + list(VIT_CASES)))
     a = ap.parse_args()
     torch.set_num_threads(8)
+    here = os.path.dirname(os.path.abspath(__file__))
     for nm in a.which.split(","):
-        if nm == "rm_tiny":
+        if nm.startswith("autocast:"):          # e.g. autocast:c1+c2+c3s+int_base+mores_base
+            run_autocast_goldens(here, nm[len("autocast:"):].split("+"))
+        elif nm in FULLSIZE:
+            run_fullsize_case(nm, here)
+        elif nm == "rm_tiny":
             run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)))
         elif nm == "rm_fuse_tiny":
             run_rerankmodel_case(os.path.dirname(os.path.abspath(__file__)), name="rm_fuse_tiny", fusion=True)

@@ -74,3 +74,76 @@ def test_two_rank_gather_matches_single_process(n_pairs, K):
     for rank, l1, l2, order in res:
         assert l1 == table.tolist() and l2 == (table * 2).tolist()
         assert order == want_order
+
+
+class _CpuEngine:
+    """CPU stand-in with RerankEngine's interface (forward_ids with pair_range / head): logit of pair i is a fixed
+    function of its token ids, so any slicing or ordering mistake in sharded_forward shows up in the numbers."""
+
+    def __init__(self, loss_fn):
+        self.arch = {"loss_fn": loss_fn}
+        self.calls = []
+
+    def forward_ids(self, ids, am, tt, Bq, K, cls, pat, labels, pair_range=None, want_loss=True, **kw):
+        b, e = pair_range
+        self.calls.append((b, e))
+        N = ids.shape[0]
+        l1 = torch.full((N,), float("nan"))
+        l2 = torch.full((N,), float("nan"))
+        f = (ids[b:e].double() * torch.arange(1, ids.shape[1] + 1)).sum(1)
+        l1[b:e] = torch.sin(f).float()
+        l2[b:e] = torch.cos(f).float()
+        return dict(logits=l1, logits2=l2)
+
+    def head(self, l1, l2, labels, Bq, K, want_scores=False, want_order=True):
+        assert torch.isfinite(l1).all()                      # every slice arrived
+        ranked = l2 if self.arch["loss_fn"] == "2H_BCE" else l1
+        order = torch.tensor([O.rank_descending_stable(r) for r in ranked.view(Bq, K).tolist()], dtype=torch.int32)
+        return dict(order=order, scores=torch.sigmoid(ranked) if want_scores else None,
+                    loss=ranked.double().sum().float())
+
+
+def _engine_worker(rank, world, port, Bq, K, loss_fn, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rmr_amd.sharding import shard_range, sharded_forward
+        ids = torch.randint(1, 1000, (Bq * K, 16), generator=torch.Generator().manual_seed(3))
+        eng = _CpuEngine(loss_fn)
+        outs = []
+        for _ in range(2):                                   # second call reuses the preallocated gather buffers
+            out = sharded_forward(eng, ids, ids, ids, Bq, K, want_scores=True)
+            outs.append((out["logits"].clone(), None if out.get("logits2") is None else out["logits2"].clone(),
+                         out["order"].clone()))
+        b, e = shard_range(Bq * K, rank, world)
+        assert eng.calls == ([(b, e)] * 2 if e > b else [])   # an empty slice never reaches the engine
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][:1], outs[1][:1])) and torch.equal(outs[0][2], outs[1][2])
+        q.put((rank, outs[0][0].tolist(), None if outs[0][1] is None else outs[0][1].tolist(), outs[0][2].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Bq,K,loss_fn", [(2, 5, "BCE"), (3, 3, "2H_BCE"), (1, 101, "negative_sampling"), (1, 1, "BCE")])
+def test_sharded_forward_with_an_engine_matches_single_rank(Bq, K, loss_fn):
+    """world 2 over gloo through rmr_amd.sharding.sharded_forward itself: ragged N % world != 0, the two-head variant's
+    second logit vector in the same collective, one pair for two ranks (an empty slice)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_engine_worker, args=(r, world, port, Bq, K, loss_fn, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ids = torch.randint(1, 1000, (Bq * K, 16), generator=torch.Generator().manual_seed(3))
+    ref = _CpuEngine(loss_fn).forward_ids(ids, ids, ids, Bq, K, None, None, None, pair_range=(0, Bq * K))
+    want = ref["logits2"] if loss_fn == "2H_BCE" else ref["logits"]
+    want_order = [O.rank_descending_stable(r) for r in want.view(Bq, K).tolist()]
+    for rank, l1, l2, order in res:
+        assert l1 == ref["logits"].tolist()
+        if loss_fn == "2H_BCE":
+            assert l2 == ref["logits2"].tolist()
+        assert order == want_order
