@@ -43,3 +43,43 @@ def arch_from_cfg(cfg: O.OracleConfig, vision: bool, compute_dtype: str = "bf16"
                 vision_hidden=cfg.vision_hidden, prefix_len=cfg.prefix_len, n_patches=cfg.n_patches,
                 map_layers=cfg.map_layers, cross_attn_len=cfg.cross_attn_len, loss_fn=cfg.loss_fn,
                 pos_weight=cfg.pos_weight, compute_dtype=compute_dtype)
+
+
+def autocast_drift(name):
+    """max |bf16-autocast logits - fp32 logits| of the stock-HF assembly for a golden case (tests/golden/autocast.npz):
+    how far the reference's OWN arithmetic (Lightning precision='bf16') sits from its fp32 forward."""
+    z = np.load(os.path.join(GOLDEN, "autocast.npz"), allow_pickle=False)
+    return float(z[f"{name}.drift_vs_fp32"]), torch.from_numpy(z[f"{name}.logits"])
+
+
+def bf16_gate(name):
+    """Gate of the bf16-operand mode against the fp32 goldens: 1e-3 (north_star) or, where the reference's own bf16-mixed
+    forward is further than that from fp32, 1.5x the reference's drift on the same case (one draw of a ~2e-3 rounding
+    noise against another: the factor keeps the gate from being a coin flip; the aggregate over all cases must not exceed
+    the reference's, test_bf16_drift_is_not_worse_than_the_references_own_autocast)."""
+    return max(1e-3, 1.5 * autocast_drift(name)[0])
+
+
+def load_fullsize(name):
+    """Full-size goldens (make_golden.py run_fullsize_case): returns (cfg, weights, per-query list of dicts with the
+    regenerated pool inputs and the stored fp32 / autocast pool logits)."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    kw = ast.literal_eval(str(z["cfg_json"]))
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = "BCE"
+    vision, S, pool = bool(z["vision"]), int(z["S"]), int(z["pool"])
+    w = O.make_weights(cfg, seed=0, vision=vision, gain=float(z["gain"]))
+    qs = []
+    for qi in range(int(z["nq"])):
+        seed = int(z[f"q{qi}.seed"])
+        ids, am, tt = O.make_pair_batch(cfg, 1, pool, S, seed=seed, regime="realistic")
+        ids[:, 1:33] = ids[0, 1:33]
+        assert int(ids.sum()) == int(z[f"q{qi}.ids_checksum"]), "synthetic input generator drifted"
+        img = O.make_image_feats(cfg, 1, seed=seed) if vision else (None, None)
+        q = dict(ids=ids, am=am, tt=tt, img=img, fp32=torch.from_numpy(z[f"q{qi}.pool_logits"]),
+                 autocast=torch.from_numpy(z[f"q{qi}.pool_logits_autocast"]))
+        for k in ("selected", "positive_list_index", "gap_5_6"):
+            if f"q{qi}.{k}" in z.files:
+                q[k] = z[f"q{qi}.{k}"]
+        qs.append(q)
+    return cfg, w, vision, qs

@@ -98,3 +98,33 @@ def test_listwise_head_and_limits(Bq):
     a = eng.head(x.reshape(-1).cuda(), None, None, Bq, K)["loss"].item()
     b = eng.head(x.reshape(-1).cuda(), None, None, Bq, K)["loss"].item()
     assert a == b and math.isfinite(a)
+
+
+def test_device_head_and_rank_against_reference_executed_fixtures():
+    """The fixtures of tests/golden/reference_fn.npz were produced by executing the reference's own
+    prepare_logits_labels / initialise_loss_fn and its `sorted(zip(docs, logits), reverse=True)`; the device head
+    (rr_head) must reproduce the loss values and the exact orders."""
+    import os
+
+    import numpy as np
+
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "reference_fn.npz"), allow_pickle=False)
+    for i in range(int(z["n_head_cases"])):
+        p = f"head{i}."
+        loss_fn = str(z[p + "loss_fn"])
+        pw = None if np.isnan(z[p + "pos_weight"]) else float(z[p + "pos_weight"])
+        Bq, K = int(z[p + "Bq"]), int(z[p + "K"])
+        eng = _engine(loss_fn, pw)
+        l1, l2 = torch.from_numpy(z[p + "l1"]).reshape(-1).cuda(), torch.from_numpy(z[p + "l2"]).reshape(-1).cuda()
+        lab = torch.from_numpy(z[p + "labels_in"]).cuda() if z[p + "labels_in"].size else None
+        # rr_head takes (ranked logits, first head): classifier1 is head 0 of the 2H_BCE pair, classifier2 the ranked one
+        r = eng.head(l2 if loss_fn == "2H_BCE" else l1, l1 if loss_fn == "2H_BCE" else None, lab, Bq, K)
+        torch.cuda.synchronize()
+        want = float(z[p + "loss"])
+        assert abs(r["loss"].item() - want) <= 3e-6 * max(1.0, abs(want)), (p, r["loss"].item(), want)
+    logits, order = z["met.logits"], z["met.order"]
+    eng = _engine("BCE")
+    r = eng.head(torch.from_numpy(logits).reshape(-1).cuda(), None, None, logits.shape[0], logits.shape[1])
+    torch.cuda.synchronize()
+    assert r["order"].cpu().tolist() == order.tolist()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, O, arch_from_cfg
+from helpers import GOLDEN, O, arch_from_cfg, autocast_drift, bf16_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -55,8 +55,10 @@ def test_interaction_matches_golden_and_oracle(name, dtype):
     assert torch.isfinite(logits).all()
     if dtype == "fp16":
         assert d32 <= 1e-3 and demu <= 1e-3
-    else:
-        assert d32 <= 8e-3 and demu <= 4e-3
+    else:     # bf16 operands: against the reference's own bf16-autocast drift on the same case (tests/golden/autocast.npz)
+        gate = bf16_gate(name)
+        print(f"   bf16 gate {gate:.2e}")
+        assert d32 <= gate and demu <= 2 * gate     # demu: two draws of the same rounding noise
     assert abs(r["loss"].item() - float(g["loss"])) < 1e-2
     assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in logits.view(Bq, K).tolist()]
 

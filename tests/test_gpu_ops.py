@@ -475,3 +475,32 @@ def test_ring_kernels_ragged_multi_tile(lib, variant, M, N, K):
     assert torch.isfinite(out16.float()).all() and (e16 <= 1.2e-2 * (1 + ref.abs())).all(), e16.max().item()
     e32 = (out32 - (ref + R)).abs()
     assert torch.isfinite(out32).all() and (e32 <= 2e-4 * (1 + ref.abs())).all(), e32.max().item()
+
+
+@pytest.mark.parametrize("variant", [-1, 0])     # -1: the production heuristic (persistent ring), 0: the 128x128 kernel
+def test_gemm_operand_beyond_4_gib(lib, variant):
+    """A of 4.3 GB (700 000 rows x 3072, the FFN-down operand of ~1 370 pairs at S = 512): row addresses are a 64-bit
+    scalar tile origin plus a 32-bit in-tile offset, so nothing wraps.  Checked on row blocks before, across and after the
+    4 GiB boundary (row 699 050) and on the last, partial tile."""
+    M, N, K = 700_000, 768, 3072
+    assert M * K * 2 > 1 << 32
+    A = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for r0 in range(0, M, 100_000):                                       # fill in chunks (keeps the fp32 temporary small)
+        A[r0: r0 + 100_000] = torch.randn(min(100_000, M - r0), K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.03).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    try:
+        assert lib.rr_set_gemm_variant(variant) == 0
+        assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, 0, out.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.rr_set_gemm_variant(-1)
+    edge = (1 << 32) // (K * 2)
+    for r0 in (0, 350_000, edge - 300, edge + 300, M - 300):
+        rows = slice(r0, min(M, r0 + 300))
+        ref = A[rows].float() @ W.float().t() + b
+        err = (out[rows].float() - ref).abs()
+        assert torch.isfinite(out[rows].float()).all()
+        assert (err <= 1.2e-2 * (1 + ref.abs())).all(), f"rows {r0}: max err {err.max().item()}"
