@@ -65,9 +65,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-pairs", type=int, default=100, help="pairs of the CPU-baseline sample (one query of K = 100)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end per-query window (N = 1)")
-    ap.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp16"],
-                    help="16-bit MFMA operand type of the timed run (north_star: bf16)")
-    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra fp16-operand timing (N=1 only)")
+    ap.add_argument("--compute-dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="16-bit MFMA operand type of the timed run.  Default fp16: the mode whose logits are within 1e-3 of the "
+                         "fp32 reference forward on every golden (same MFMA rate as bf16, 3 more mantissa bits; accumulation, "
+                         "residual stream, LayerNorm, softmax stay fp32).  bf16 (what the reference's autocast uses) drifts "
+                         "2e-3..1e-2 from fp32 in ANY implementation, the reference's own included (tests/golden/autocast.npz)")
+    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra timing of the other operand type (N=1 only)")
     a = ap.parse_args(argv)
     if a.encoder == "bert-large":
         a.workload = "c5"
@@ -308,7 +311,7 @@ def main():
             "parity": {"bf16": "|logit - fp32 stock-HF| <= max(1e-3, the bf16-autocast reference's own drift) on every golden "
                                "(tests/test_gpu_forward.py, tests/golden/autocast.npz)",
                        "fp16": "|logit - fp32 stock-HF| <= 1e-3 on every golden (compute_dtype=fp16; throughput below)",
-                       "mode_meeting_1e-3_vs_fp32": "fp16"},
+                       "mode_meeting_1e-3_vs_fp32": "fp16", "this_line": args.compute_dtype},
             "gflop_per_pair": fpp / 1e9,
             "whole_path_tflops_per_gpu": pairs_per_s * fpp / 1e12 / world,
             "whole_path_frac_of_bf16_peak": pairs_per_s * fpp / 1e12 / world / PEAK_BF16_TFLOPS,
@@ -356,11 +359,12 @@ def main():
                                               "window": "pinned host ids/masks/features -> HBM, rr_forward (K pairs, device-side "
                                                         "stable top-K), logits + order -> host; the reference's 'Rerank time' "
                                                         "window (1.40 s per query published for monoPreFLMR-B on its GPU)"}
-        if world == 1 and not args.no_alt_dtype and args.compute_dtype == "bf16" and not args.fp8:
-            # same kernels with fp16 MFMA operands (the mode that meets 1e-3 against the fp32 reference logits)
+        if world == 1 and not args.no_alt_dtype and not args.fp8:
+            # the same kernels with the other 16-bit operand type
+            alt = "bf16" if args.compute_dtype == "fp16" else "fp16"
             del eng
             torch.cuda.empty_cache()
-            eng2 = rmr_amd.RerankEngine(dict(arch, compute_dtype="fp16"), dev)
+            eng2 = rmr_amd.RerankEngine(dict(arch, compute_dtype=alt), dev)
             eng2.load_state_dict(sd)
             for _ in range(max(1, args.warmup)):
                 eng2.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
@@ -369,9 +373,8 @@ def main():
             for _ in range(args.steps):
                 eng2.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
             torch.cuda.synchronize(dev)
-            res["fp16_operand_mode"] = {"value": N * args.steps / (time.perf_counter() - t1), "unit": "pairs/s",
-                                        "note": "compute_dtype=fp16: logits within 1e-3 of the fp32 HF goldens "
-                                                "(tests/test_gpu_forward.py)"}
+            res[alt + "_operand_mode"] = {"value": N * args.steps / (time.perf_counter() - t1), "unit": "pairs/s",
+                                          "note": res["parity"][alt]}
             del eng2
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(arch, sd, S, vision, args.cpu_pairs)

@@ -314,8 +314,19 @@ int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, floa
  * (exact and order-independent), from which the caller derives scale = amax / 448. */
 int rr_op_quantize_fp8(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream);
 int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_stream);
+/* LayerNorm folded into the consumer GEMM (north_star "fused LayerNorm+QKV"), the two halves stand-alone:
+ *   rr_op_gemm_resid_lnprep: out_f32 = A W^T + bias + resid (as rr_op_gemm_resid_f32) and, from the same epilogue, x16_out =
+ *     the 16-bit copy of those rows plus per-row LayerNorm statistics stats_out[row] = (mean, rstd) of out_f32's rows
+ *     (merged from per-128-column partials in part_scratch [M, ceil(N/128), 2]).  N % 8 == 0.
+ *   rr_op_gemm_lnfold: out = epi(rstd_m * (A_raw W_folded^T - mean_m * csum) + dvec), epilogue 0 = 16-bit, 1 = 16-bit erf-GELU,
+ *     2 = f32; with W_folded = 16bit(W * gamma), csum_n = sum_k W_folded[n,k], dvec = W beta + b this is
+ *     epi(LayerNorm(x) W^T + b) for the raw rows x whose 16-bit copy is A_raw. */
+int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N, int Kd,
+                            float eps, float* out_f32, uint16_t* x16_out, float* stats_out, float* part_scratch, void* hip_stream);
+int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
+                      int M, int N, int Kd, int epilogue, void* out, void* hip_stream);
 int rr_set_gemm_variant(int variant);
-int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
+int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */

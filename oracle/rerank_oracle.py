@@ -154,22 +154,77 @@ def multi_head_attention_bf16(q: Tensor, k: Tensor, v: Tensor, heads: int, add_m
 _MHA = [multi_head_attention]
 
 
+_FOLD = [False]
+
+
 class device_rounding:
     """`with device_rounding(dtype) as mm:` — run the oracle with the device's 16-bit rounding points
-    (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16")."""
+    (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16").  `fold` (default: as the device):
+    the encoder stacks (`encoder_stack`) run with LayerNorm folded into the consumer GEMMs, i.e. the 16-bit operand
+    of QKV / FFN-up is the RAW pre-LayerNorm row and the normalisation happens on the fp32 accumulators."""
 
-    def __init__(self, dtype=torch.bfloat16):
-        self.dtype = dtype
+    def __init__(self, dtype=torch.bfloat16, fold: bool = True):
+        self.dtype, self.fold = dtype, fold
 
     def __enter__(self):
         _MHA.append(multi_head_attention_bf16)
         _RDT.append(self.dtype)
+        _FOLD.append(self.fold)
         return mm_bf16
 
     def __exit__(self, *a):
         _MHA.pop()
         _RDT.pop()
+        _FOLD.pop()
         return False
+
+
+def folded_linear(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, W: Tensor, b: Optional[Tensor]) -> Tensor:
+    """Device form of Linear(LayerNorm(x)) with the LayerNorm folded into the GEMM (csrc/gemm_bf16.hip LnResid):
+    rstd * (x16 W'^T - mean * c) + d,  W' = 16bit(W * gamma),  c = row sums of W',  d = W beta + b;  mean / variance of the
+    fp32 row (the device merges per-128-column (mean, M2) partials: same quantities, fp32)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    Wp = _bf(W * gamma[None, :])
+    c = Wp.double().sum(1).float()
+    d = (W.double() @ beta.double()).float()
+    if b is not None:
+        d = d + b
+    return rstd * (_bf(x) @ Wp.t() - mu * c) + d
+
+
+def encoder_stack(h: Tensor, w: Dict[str, Tensor], prefix: str, n_layers: int, heads: int, eps: float,
+                  add_mask: Optional[Tensor], mm=None, taps: Optional[dict] = None, tap_name: str = "") -> Tensor:
+    """`n_layers` post-LN BertLayers `{prefix}.{i}` on the embedding output `h`.  Plain fp32 (or, with `mm`, the unfolded
+    rounding points) = a loop over bert_layer.  Under device_rounding(fold=True) it mirrors the device's folded dataflow:
+    layer 0's QKV takes the normalised embedding rows; every FFN-up and every later QKV takes the raw rows of the
+    LayerNorm's input with the LayerNorm applied after the GEMM; residuals are the exact fp32 LayerNorm values."""
+    if not (_FOLD[-1] and mm is not None):
+        for i in range(n_layers):
+            h = bert_layer(h, w, f"{prefix}.{i}", heads, eps, add_mask, mm=mm)
+            if taps is not None:
+                taps[f"{tap_name}{i}"] = h
+        return h
+    pre = g = b = None                      # raw input of the previous output LayerNorm and its affine
+    for i in range(n_layers):
+        p = f"{prefix}.{i}"
+        if pre is None:
+            q, k, v = (linear(h, w, p + ".attention.self." + n, mm) for n in ("query", "key", "value"))
+        else:
+            q, k, v = (folded_linear(pre, g, b, eps, w[p + f".attention.self.{n}.weight"], w[p + f".attention.self.{n}.bias"])
+                       for n in ("query", "key", "value"))
+        ctx = _MHA[-1](q, k, v, heads, add_mask)
+        pre1 = linear(ctx, w, p + ".attention.output.dense", mm) + h
+        g1, b1 = w[p + ".attention.output.LayerNorm.weight"], w[p + ".attention.output.LayerNorm.bias"]
+        a = F.layer_norm(pre1, (pre1.shape[-1],), g1, b1, eps)                      # fp32 residual value
+        inter = gelu_erf(folded_linear(pre1, g1, b1, eps, w[p + ".intermediate.dense.weight"], w[p + ".intermediate.dense.bias"]))
+        pre = linear(inter, w, p + ".output.dense", mm) + a
+        g, b = w[p + ".output.LayerNorm.weight"], w[p + ".output.LayerNorm.bias"]
+        h = F.layer_norm(pre, (pre.shape[-1],), g, b, eps)
+        if taps is not None:
+            taps[f"{tap_name}{i}"] = h
+    return h
 
 
 def extended_mask(mask01: Tensor) -> Tensor:
@@ -224,11 +279,7 @@ def text_encoder(cfg: OracleConfig, w: Dict[str, Tensor], input_ids: Tensor, att
     if taps is not None:
         taps["text_emb"] = h
     am = extended_mask(attention_mask)
-    for i in range(cfg.layers):
-        h = bert_layer(h, w, f"{p}.encoder.layer.{i}", cfg.heads, cfg.ln_eps, am, mm=mm)
-        if taps is not None:
-            taps[f"text_layer_{i}"] = h
-    return h
+    return encoder_stack(h, w, f"{p}.encoder.layer", cfg.layers, cfg.heads, cfg.ln_eps, am, mm, taps, "text_layer_")
 
 
 def token_mask(input_ids: Tensor) -> Tensor:
@@ -286,10 +337,7 @@ def cross_encoder(cfg: OracleConfig, w: Dict[str, Tensor], inputs_embeds: Tensor
         if attention_adj.dim() == 3:
             attention_adj = attention_adj[:, None]
         am = am + attention_adj
-    for i in range(cfg.ce_layers):
-        h = bert_layer(h, w, f"{p}.encoder.layer.{i}", cfg.ce_heads, cfg.ln_eps, am, mm=mm)
-        if taps is not None:
-            taps[f"ce_layer_{i}"] = h
+    h = encoder_stack(h, w, f"{p}.encoder.layer", cfg.ce_layers, cfg.ce_heads, cfg.ln_eps, am, mm, taps, "ce_layer_")
     cls = h[:, 0]                                                           # utils.py:102
     return linear(cls, w, "reranker.classifier1"), linear(cls, w, "reranker.classifier2")
 

@@ -69,6 +69,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
            o16 ? o16 + (size_t)row * cols : nullptr, dt);
 }
 
+// ---- folded LayerNorm: merge the per-128-column-group (mean, M2) partials a residual GEMM's epilogue left behind into
+// (mean, rstd) per row.  Equal-weight groups except the last: Chan et al. pairwise update, evaluated in group order
+// (deterministic).  One thread per row; rows x nparts x 8 bytes in, rows x 8 bytes out.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int nparts, int cols, float eps,
+                                                          int rows, float2* __restrict__ stats) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = part + (size_t)row * nparts;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int g = 0; g < nparts; ++g) {
+    const float2 v = p[g];
+    const float nb = (float)min(128, cols - g * 128), nt = n + nb;
+    const float delta = v.x - mean;
+    mean += delta * (nb / nt);
+    m2 += v.y + delta * delta * (n * nb / nt);
+    n = nt;
+  }
+  stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / n + eps));
+}
+
 // ---- BertEmbeddings from ids: word[id] + type[tt] + pos[s] -> LN
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                        const float* __restrict__ word, const float* __restrict__ pos,
@@ -392,6 +412,13 @@ hipError_t rr_launch_layernorm_stats(const float* x, const float* gamma, const f
   if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4 || !stats_out) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
                      out_f32, out_bf16, dt, (float2*)stats_out);
+  return hipGetLastError();
+}
+
+hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || nparts != (cols + 127) / 128 || !part || !stats) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float2*)part, nparts, cols, eps,
+                     rows, (float2*)stats);
   return hipGetLastError();
 }
 

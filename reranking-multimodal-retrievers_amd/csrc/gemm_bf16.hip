@@ -103,7 +103,45 @@ struct LnResid {
   const float2* stats;   // [rows] (mean, rstd) or nullptr = `resid` already holds the residual values
   const float* gamma;
   const float* beta;
+  // LayerNorm folded into the CONSUMER GEMM (north_star "fused LayerNorm+QKV"):
+  //   LN(x) W^T + b = rstd * (x W'^T - mean * c) + d,  W' = 16bit(W * gamma), c_n = sum_k W'_nk, d_n = sum_k beta_k W_nk + b_n
+  // producer side (EPI_BIAS_RESID_F32 only): besides the fp32 rows the epilogue writes the same values as 16-bit rows
+  // `x16` (the consumer's A operand) and, per row and 128-column group, (group mean, sum of squared deviations from it);
+  // ln_finalize_kernel merges the groups into (mean, rstd).  consumer side: `in_stats` (mean, rstd) per A row and
+  // `csum` = c; `bias` then carries d.
+  bf16_t* x16;
+  int ldx;
+  float2* part;          // [rows][nparts]
+  int nparts;            // ceil(N / 128)
+  const float2* in_stats;
+  const float* csum;
 };
+// sum over aligned groups of 32 consecutive lanes (= one 128-column group of a row in the staged epilogues)
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// Producer side of the folded LayerNorm for one 16-byte chunk (4 consecutive columns gcol..gcol+3 of row gm) of the
+// staged fp32 epilogue; lanes of an aligned group of 32 hold the 32 chunks of one 128-column group of ONE row.  Every
+// lane of the wave must call this (the reductions are cross-lane); `valid` masks rows/columns outside the matrix.
+template <int DT>
+__device__ __forceinline__ void fold_emit(const LnResid& ln, float4 f, bool valid, int gm, int gcol, int N) {
+  if (valid) *(uint2*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint2(pack2<DT>(f.x, f.y), pack2<DT>(f.z, f.w));
+  const int grp = gcol >> 7;
+  const float cnt = (float)min(128, N - (grp << 7));                 // columns of this group inside the matrix
+  const float s = valid ? (f.x + f.y) + (f.z + f.w) : 0.f;
+  const float m = group32_sum(s) / cnt;
+  const float a = f.x - m, b = f.y - m, c = f.z - m, d = f.w - m;
+  const float q = valid ? (a * a + b * b) + (c * c + d * d) : 0.f;
+  const float m2 = group32_sum(q);
+  if (valid && (threadIdx.x & 31) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(m, m2);
+}
+// Consumer side: (acc - mean * c) * rstd for 4 consecutive columns of a row with statistics st = (mean, rstd)
+__device__ __forceinline__ f32x4 fold_apply(f32x4 acc, float2 st, float4 cs) {
+  return f32x4{(acc[0] - st.x * cs.x) * st.y, (acc[1] - st.x * cs.y) * st.y, (acc[2] - st.x * cs.z) * st.y,
+               (acc[3] - st.x * cs.w) * st.y};
+}
 __device__ __forceinline__ float4 ln_apply(float4 x, const LnResid& ln, int gm, int gn) {
   if (!ln.stats) return x;
   const float2 st = ln.stats[gm];
@@ -248,12 +286,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
     // (1) every wave finishes its own values first (bias + activation, final dtype) so that the GELU/tanh VALU work
     //     of all 8 waves runs concurrently rather than one row group at a time
     uint2 pk[F32_OUT ? 1 : NT][F32_OUT ? 1 : MT];
+    float2 fst[MT];          // folded LayerNorm, consumer side: (mean, rstd) of this lane's rows
+    if (ln.in_stats) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fst[mt] = ln.in_stats[min(m0 + wm * TM + mt * 16 + (lane & 15), M - 1)];
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
       const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ln.in_stats && gn < N) cs = *(const float4*)(ln.csum + gn);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if (ln.in_stats) acc[nt][mt] = fold_apply(acc[nt][mt], fst[mt], cs);
         float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
               v3 = acc[nt][mt][3] + bv.w;
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
@@ -280,33 +326,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       }
       lds_barrier();
       const int row_base = m0 + (F32_OUT ? pass * TM : 0);
+      static_assert((ROWS * CPR) % NTHR == 0, "every thread runs the same number of stream-out steps (cross-lane sums below)");
 #pragma unroll 4
       for (int i = tid; i < ROWS * CPR; i += NTHR) {
         const int r = i / CPR, c = i - r * CPR;
         const int gm = row_base + r, gcol = n0 + c * (16 / ES);
-        if (gm < M && gcol < N) {
+        const bool ok = gm < M && gcol < N;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
           uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
           if (EPI == EPI_BIAS_RESID_F32) {
             const float4 rv = ln_apply(*(const float4*)(resid + (size_t)gm * ldr + gcol), ln, gm, gcol);
-            float4 f = __builtin_bit_cast(float4, v);
+            f = __builtin_bit_cast(float4, v);
             f.x += rv.x; f.y += rv.y; f.z += rv.z; f.w += rv.w;
             v = __builtin_bit_cast(uint4, f);
           }
           *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
         }
+        // folded LayerNorm, producer side (an aligned group of 32 lanes = the 32 chunks of one 128-column group of a row)
+        if constexpr (EPI == EPI_BIAS_RESID_F32 && CPR % 32 == 0) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
       }
       if (pass + 1 < NPASS) lds_barrier();
     }
   } else {
+  float2 fst[MT];            // folded LayerNorm, consumer side: (mean, rstd) of this lane's rows
+  if (ln.in_stats) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fst[mt] = ln.in_stats[min(m0 + wm * TM + mt * 16 + (lane & 15), M - 1)];
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int gn = n0 + wn * TN + nt * 16 + (lane >> 4) * 4;
     if (gn >= N) continue;
     float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 cs = ln.in_stats ? *(const float4*)(ln.csum + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int gm = m0 + wm * TM + mt * 16 + (lane & 15);
       if (gm >= M) continue;
+      if (ln.in_stats) acc[nt][mt] = fold_apply(acc[nt][mt], fst[mt], cs);
       float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
             v3 = acc[nt][mt][3] + bv.w;
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
@@ -572,6 +630,24 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 
   // ---- epilogue (quadrant q = 2*hA + hB): rows hA*128 + wr*64 + mt*16 + (lane&15), cols hB*128 + wc*32 + nt*16 + (lane>>4)*4
   constexpr bool F32_OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_RESID_F32);
+  // folded LayerNorm, consumer side (both epilogue forms): (mean, rstd) of the 8 rows this lane owns
+  float2 fst[2][4];
+  if (ln.in_stats) {
+#pragma unroll
+    for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        fst[hA][mt] = ln.in_stats[min(m0 + hA * 128 + wr * 64 + mt * 16 + (lane & 15), M - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int gn = n0 + (q & 1) * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+        const float4 cs = gn < N ? *(const float4*)(ln.csum + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[q][nt][mt] = fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs);
+      }
+  }
   if constexpr (LDS_EPI) {
     constexpr int ES = F32_OUT ? 4 : 2;
     constexpr int PITCH = BN * ES + 16;
@@ -647,19 +723,23 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
             rv[u] = x;
           }
         }
+        static_assert((ROWS * CPR) % (512 * UNR) == 0, "every thread runs every step (cross-lane sums below)");
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int i = i0 + u * 512, r = i / CPR, c = i - r * CPR;
           const int gm = row_base + r, gcol = n0 + c * (16 / ES);
-          if (i < ROWS * CPR && gm < M && gcol < N) {
+          const bool ok = i < ROWS * CPR && gm < M && gcol < N;
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
             uint4 v = *(const uint4*)(lds + r * PITCH + c * 16);
             if (EPI == EPI_BIAS_RESID_F32) {
-              float4 f = __builtin_bit_cast(float4, v);
+              f = __builtin_bit_cast(float4, v);
               f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
               v = __builtin_bit_cast(uint4, f);
             }
             *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
           }
+          if (EPI == EPI_BIAS_RESID_F32) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }   // folded LayerNorm, producer side
         }
       }
       if (pass + 1 < NPASS) lds_barrier();
@@ -980,6 +1060,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     constexpr int ROWS = F32_OUT ? 64 : 128;
     static_assert(ROWS * PITCH <= 5 * HALF, "staging image must fit above the five prefetch slots");
     char* const stg = lds + 5 * HALF;
+    // folded LayerNorm, consumer side: A held raw pre-LayerNorm rows; (mean, rstd) of the 8 rows this lane owns
+    float2 fst[2][4];
+    if (ln.in_stats) {
+#pragma unroll
+      for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          fst[hA][mt] = ln.in_stats[min(cm0 + hA * 128 + wr * 64 + mt * 16 + (lane & 15), M - 1)];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int hB = q & 1;
@@ -987,8 +1076,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       for (int nt = 0; nt < 2; ++nt) {
         const int gn = cn0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
         const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ln.in_stats && gn < N) cs = *(const float4*)(ln.csum + gn);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+          if (ln.in_stats) acc[q][nt][mt] = fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs);
           float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
                 v3 = acc[q][nt][mt][3] + bv.w;
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
@@ -1055,16 +1147,21 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       for (int u = 0; u < UNR; ++u) {
         const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
         const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
-        if (gm < M && gcol < N) {
+        const bool ok = gm < M && gcol < N;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
           uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
           if (!F32_OUT && (tid & 256)) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/32 + 16u: bit 3 of r = bit 8 of tid
           if (EPI == EPI_BIAS_RESID_F32) {
-            float4 f = __builtin_bit_cast(float4, v);
+            f = __builtin_bit_cast(float4, v);
             f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
             v = __builtin_bit_cast(uint4, f);
           }
           *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
         }
+        // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
+        // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)
+        if (EPI == EPI_BIAS_RESID_F32) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
       }
       lds_barrier();                                       // staging image consumed (next pass / next tile may overwrite it)
     }
@@ -1256,24 +1353,32 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
   return 0;
 }
 
-hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
-                             const float* resid, int ldr, const float* ln_stats, const float* ln_gamma,
-                             const float* ln_beta, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
-                             hipStream_t st);
-
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
                           int epilogue, int dt, hipStream_t st) {
-  return rr_launch_gemm_ln(A, lda, W, ldw, bias, resid, ldr, nullptr, nullptr, nullptr, C, ldc, M, N, Kd, epilogue, dt, st);
+  return rr_launch_gemm_fold(A, lda, W, ldw, bias, resid, ldr, nullptr, nullptr, nullptr, GemmFold{}, C, ldc, M, N, Kd, epilogue, dt, st);
 }
 
 hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                              const float* resid, int ldr, const float* ln_stats, const float* ln_gamma,
                              const float* ln_beta, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
                              hipStream_t st) {
+  return rr_launch_gemm_fold(A, lda, W, ldw, bias, resid, ldr, ln_stats, ln_gamma, ln_beta, GemmFold{}, C, ldc, M, N, Kd, epilogue, dt, st);
+}
+
+hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
+                               const float* resid, int ldr, const float* ln_stats, const float* ln_gamma,
+                               const float* ln_beta, const GemmFold& fold, void* C, int ldc, int M, int N, int Kd,
+                               int epilogue, int dt, hipStream_t st) {
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (ln_stats && (epilogue != EPI_BIAS_RESID_F32 || !ln_gamma || !ln_beta)) return hipErrorInvalidValue;
-  const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta};
+  // folded LayerNorm: producer outputs belong to the fp32 residual epilogue; the consumer form needs its column sums
+  if (fold.x16 && (epilogue != EPI_BIAS_RESID_F32 || !fold.part || fold.nparts != (N + 127) / 128 || (fold.ldx & 3) || (N & 7)))
+    return hipErrorInvalidValue;
+  if ((fold.in_stats != nullptr) != (fold.csum != nullptr)) return hipErrorInvalidValue;
+  if (fold.in_stats && (epilogue == EPI_BIAS_RESID_F32)) return hipErrorInvalidValue;
+  const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta, fold.x16, fold.ldx, (float2*)fold.part, fold.nparts,
+                   (const float2*)fold.in_stats, fold.csum};
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
   if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;
@@ -1289,9 +1394,14 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     v = tiles256 >= 512 ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
   }
+  if (fold.x16) {   // the producer side of the folded LayerNorm lives in the LDS-staged epilogues only
+    if (v == 0) v = 20;
+    else if (v != 10 && v != 12 && v != 14 && v != 20) return hipErrorInvalidValue;
+  }
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 20: return launch_cfg<128, 128, 2, 2, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 2: return launch_cfg<256, 256, 2, 4, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 10: return launch_cfg<256, 256, 2, 4, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
@@ -1304,6 +1414,7 @@ hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   return launch_cfg<BM_, BN_, WM_, WN_, ST_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln)
   switch (v) {
     case 0: RR_CFG(128, 128, 2, 2, 2);
+    case 20: return launch_cfg<128, 128, 2, 2, 2, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 1: RR_CFG(128, 128, 2, 2, 4);
     case 2: RR_CFG(256, 256, 2, 4, 2);
     case 3: RR_CFG(256, 128, 4, 2, 3);

@@ -30,8 +30,6 @@ hipError_t rr_launch_interaction_bias(const float*, const float*, int, int, int,
                                       hipStream_t);
 hipError_t rr_launch_layernorm_stats(const float*, const float*, const float*, float, int, int, float*, bf16_t*, float*,
                                      int, hipStream_t);
-hipError_t rr_launch_gemm_ln(const bf16_t*, int, const bf16_t*, int, const float*, const float*, int, const float*,
-                             const float*, const float*, void*, int, int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
 hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, void*, int, int, int, int, int, hipStream_t);
@@ -98,6 +96,11 @@ struct LayerW {
   bf16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+  // LayerNorm folded into the consumer GEMM (gemm_bf16.hip LnResid): W' = 16bit(W * gamma), c = row sums of W',
+  // d = W beta + b.  wqkv_f folds the PREVIOUS layer's output LayerNorm (null for the first layer of a stack), w1_f this
+  // layer's attention-output LayerNorm.
+  bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
+  float *cqkv_f = nullptr, *dqkv_f = nullptr, *c1_f = nullptr, *d1_f = nullptr;
   // cross-attention (transformer mapping network only)
   bf16_t *wq_c = nullptr, *wkv_c = nullptr, *wo_c = nullptr;
   float *bq_c = nullptr, *bkv_c = nullptr, *bo_c = nullptr, *lncg = nullptr, *lncb = nullptr;
@@ -381,7 +384,33 @@ std::vector<float> cat(std::initializer_list<const std::vector<float>*> parts, f
     if (rc_ != RR_OK) return rc_; \
   } while (0)
 
-int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross, LayerW* L) {
+// Folded form of a Linear [N, K] (+ bias [N]) behind LayerNorm(gamma, beta) [K]: see LayerW.
+int up_folded(rr_model* m, const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& gamma,
+              const std::vector<float>& beta, bf16_t** w_out, float** c_out, float** d_out) {
+  const size_t K = gamma.size(), N = W.size() / K;
+  std::vector<uint16_t> w16(W.size());
+  std::vector<float> c(N), d(N);
+  for (size_t n = 0; n < N; ++n) {
+    double cs = 0.0, ds = 0.0;
+    for (size_t k = 0; k < K; ++k) {
+      const float wg = W[n * K + k] * gamma[k];
+      const uint16_t r = m->dt ? host_f2h(wg) : host_f2bf(wg);
+      w16[n * K + k] = r;
+      cs += (double)(m->dt ? host_h2f(r) : host_bf2f(r));          // the sum the MFMA forms for a constant row, exactly
+      ds += (double)W[n * K + k] * (double)beta[k];
+    }
+    c[n] = (float)cs;
+    d[n] = (float)(ds + (b.empty() ? 0.0 : (double)b[n]));
+  }
+  int rc = dev_alloc(m, (void**)w_out, w16.size() * 2);
+  if (rc) return rc;
+  RR_HIP(m, hipMemcpy(*w_out, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+  RR_TRY(up_f32(m, c, c_out));
+  return up_f32(m, d, d_out);
+}
+
+// prev_ln: state_dict prefix of the LayerNorm whose output feeds this layer's QKV ("" = none: first layer of a stack)
+int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross, LayerW* L, const std::string& prev_ln = "") {
   const float qs = 1.0f / sqrtf((float)(Hd / heads));   // 1/sqrt(dh): 0.125 for dh = 64 (exact in bf16)
   const std::string a = p + ".attention";
   RR_TRY(up_bf16(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs), &L->wqkv));
@@ -403,6 +432,14 @@ int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross,
   }
   RR_TRY(up_bf16(m, HT(m, p + ".intermediate.dense.weight"), &L->w1));
   RR_TRY(up_f32(m, HT(m, p + ".intermediate.dense.bias"), &L->b1));
+  if (!cross) {   // plain encoder layers: folded forms for the LayerNorm -> QKV and LayerNorm -> FFN-up seams
+    RR_TRY(up_folded(m, HT(m, p + ".intermediate.dense.weight"), HT(m, p + ".intermediate.dense.bias"),
+                     HT(m, a + ".output.LayerNorm.weight"), HT(m, a + ".output.LayerNorm.bias"), &L->w1_f, &L->c1_f, &L->d1_f));
+    if (!prev_ln.empty())
+      RR_TRY(up_folded(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs),
+                       cat({&HT(m, a + ".self.query.bias"), &HT(m, a + ".self.key.bias"), &HT(m, a + ".self.value.bias")}, qs),
+                       HT(m, prev_ln + ".weight"), HT(m, prev_ln + ".bias"), &L->wqkv_f, &L->cqkv_f, &L->dqkv_f));
+  }
   RR_TRY(up_bf16(m, HT(m, p + ".output.dense.weight"), &L->w2));
   RR_TRY(up_f32(m, HT(m, p + ".output.dense.bias"), &L->b2));
   RR_TRY(up_f32(m, HT(m, p + ".output.LayerNorm.weight"), &L->ln2g));
@@ -463,7 +500,7 @@ struct Bump {
 };
 
 struct Work {
-  float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask;
+  float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask, *lnpart;
   bf16_t *h16, *qkv, *ctx, *mid, *li16;
   // vision
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
@@ -502,6 +539,7 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   w->pre2 = b.take<float>(Rm * Hm);
   w->stats_a = b.take<float>(Rm * 2);
   w->stats_b = b.take<float>(Rm * 2);
+  w->lnpart = b.take<float>(Rm * 2 * ((Hm + 127) / 128));
   w->h16 = b.take<bf16_t>(Rm * Hm);
   w->qkv = b.take<bf16_t>(Rm * 3 * Hm);
   w->ctx = b.take<bf16_t>(Rm * Hm);
@@ -595,14 +633,43 @@ struct ResidSrc {
   RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, outb) + 4.0 * (M) * (N),                     \
          rr_launch_gemm_ln(A, lda, W, K, bias, (rs).x, N, (rs).stats, (rs).g, (rs).b, C, ldc, M, N, K,           \
                            EPI_BIAS_RESID_F32, m->dt, st))
+// residual GEMM that also emits the 16-bit copy of its rows (-> x16) and their LayerNorm statistics partials
+#define RR_GEMM_LN_PREP(m, st, A, lda, W, bias, rs, C, ldc, M, N, K, fold)                                         \
+  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, 4.0) + 4.0 * (M) * (N) + 2.0 * (M) * (N),      \
+         rr_launch_gemm_fold(A, lda, W, K, bias, (rs).x, N, (rs).stats, (rs).g, (rs).b, fold, C, ldc, M, N, K,     \
+                             EPI_BIAS_RESID_F32, m->dt, st))
+// GEMM whose A operand holds raw pre-LayerNorm rows; the LayerNorm is applied in the epilogue (folded weights)
+#define RR_GEMM_FOLDED(m, st, A, lda, Wf, dvec, fold, C, ldc, M, N, K, epi)                                         \
+  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, 2.0) + 8.0 * (M),                              \
+         rr_launch_gemm_fold(A, lda, Wf, K, dvec, nullptr, 0, nullptr, nullptr, nullptr, fold, C, ldc, M, N, K, epi, m->dt, st))
 
-// One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).  In: w.h16 (bf16 LayerNorm output of the
-// previous block) and `rs`; out: w.h16, `rs` updated to this layer's LN2 (and w.h32 when `want_h32`).
+int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
+
+// One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
+// In: the previous LayerNorm's output as MFMA operand in w.h16 — either normalised (`folded_in` false: after an embedding
+// LayerNorm, or when folding is off) or, `folded_in` true, the RAW rows of that LayerNorm's input, whose statistics are
+// rs.stats and whose affine is folded into L.wqkv_f — and `rs`, where the residual comes from.
+// Out: w.h16 / folded_in / rs for the next layer (and w.h32 + normalised w.h16 when `want_h32`: last layer of a stack).
+//
+// Folded dataflow (north_star "fused LayerNorm+QKV"): no LayerNorm kernel between the GEMMs.  The residual GEMMs
+// (attention output, FFN down) write their fp32 rows, the same rows in 16 bits and per-row statistics partials; a
+// rows x 8-byte finalize merges the partials; QKV / FFN-up read the raw 16-bit rows and apply (mean, rstd) in their
+// epilogue: LN(x) W^T + b = rstd (x W'^T - mean c) + d.
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
-              const float* key_bias, Work& w, ResidSrc& rs, bool want_h32, const float* dense_bias = nullptr,
-              int dense_ld = 0) {
+              const float* key_bias, Work& w, ResidSrc& rs, bool& folded_in, bool want_h32, bool want_f32,
+              const float* dense_bias = nullptr, int dense_ld = 0) {
   const int rows = batch * Tseq;
-  RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
+  const int nparts = (Hd + 127) / 128;
+  const bool fold = g_ln_fold && g_ln_lite && L.w1_f && (Hd % 8 == 0);
+  if (folded_in) {
+    if (!L.wqkv_f) return fail(m, RR_ERR_BAD_ARG, "internal: folded operand into a layer without folded QKV weights");
+    GemmFold f;
+    f.in_stats = rs.stats;
+    f.csum = L.cqkv_f;
+    RR_GEMM_FOLDED(m, st, w.h16, Hd, L.wqkv_f, L.dqkv_f, f, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16);
+  } else {
+    RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
+  }
   RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
          rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
                              Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld));
@@ -616,6 +683,33 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
            rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
     rs = r0;
+    folded_in = false;
+    return RR_OK;
+  }
+  if (fold) {
+    GemmFold fo;
+    fo.x16 = w.h16;
+    fo.ldx = Hd;
+    fo.part = w.lnpart;
+    fo.nparts = nparts;
+    RR_GEMM_LN_PREP(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, fo);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st));
+    GemmFold fi;
+    fi.in_stats = w.stats_a;
+    fi.csum = L.c1_f;
+    RR_GEMM_FOLDED(m, st, w.h16, Hd, L.w1_f, L.d1_f, fi, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16);
+    const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
+    RR_GEMM_LN_PREP(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, fo);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st));
+    rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
+    folded_in = true;
+    if (want_h32) {   // last layer of a stack: its consumers (CLS heads, 768->128 projection, debug taps) take normalised rows
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
+             rr_launch_layernorm(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_f32 ? w.h32 : nullptr, w.h16, m->dt, st));
+      folded_in = false;
+    }
     return RR_OK;
   }
   RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
@@ -624,10 +718,11 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   RR_GEMM(m, st, w.h16, Hd, L.w1, L.b1, nullptr, 0, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16, 2.0);
   const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
   RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
-  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_h32 ? 10.0 : 6.0) * rows * Hd,
-         rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_h32 ? w.h32 : nullptr, w.h16, w.stats_b,
-                                   m->dt, st));
+  RR_RUN(m, st, RR_K_LAYERNORM, 0.0, ((want_h32 && want_f32) ? 10.0 : 6.0) * rows * Hd,
+         rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, (want_h32 && want_f32) ? w.h32 : nullptr, w.h16,
+                                   w.stats_b, m->dt, st));
   rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
+  folded_in = false;
   return RR_OK;
 }
 
@@ -677,9 +772,10 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const 
          rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
+    bool folded = false;
     for (int l = 0; l < c.ce_layers; ++l)
-      RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs,
-                       l == c.ce_layers - 1,                // the CLS heads read the fp32 rows of the last layer
+      RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
+                       l == c.ce_layers - 1, true,          // the CLS heads read the fp32 rows of the last layer
                        adj, adj_ld));                       // attention fusion: the same bias in every layer
   }
   m->tap_ce = w.h32;
@@ -696,6 +792,7 @@ size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, cha
   w->pre2 = b.take<float>(RT * Hc);
   w->stats_a = b.take<float>(RT * 2);
   w->stats_b = b.take<float>(RT * 2);
+  w->lnpart = b.take<float>(RT * 2 * ((Hc + 127) / 128));
   w->h16 = b.take<bf16_t>(RT * Hc);
   w->qkv = b.take<bf16_t>(RT * 3 * Hc);
   w->ctx = b.take<bf16_t>(RT * Hc);
@@ -861,7 +958,8 @@ static int rr_finalize_weights_impl(rr_handle h) {
       RR_TRY(up_f32(m, HT(m, q + ".embeddings.LayerNorm.weight"), &m->ce_emb_g));
       RR_TRY(up_f32(m, HT(m, q + ".embeddings.LayerNorm.bias"), &m->ce_emb_b));
       for (int i = 0; i < c.ce_layers; ++i)
-        RR_TRY(pack_layer(m, q + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i]));
+        RR_TRY(pack_layer(m, q + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i],
+                          i ? q + ".encoder.layer." + std::to_string(i - 1) + ".output.LayerNorm" : std::string()));
     } else {
       for (int i = 0; i < c.ce_layers; ++i)
         RR_TRY(pack_layer(m, "reranker.interaction_module." + std::to_string(i), c.ce_heads, c.ce_hidden, true,
@@ -883,7 +981,8 @@ static int rr_finalize_weights_impl(rr_handle h) {
   RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.bias"), &m->emb_b));
   m->text_layers.resize(c.layers);
   for (int i = 0; i < c.layers; ++i)
-    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.heads, c.hidden, false, &m->text_layers[i]));
+    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.heads, c.hidden, false, &m->text_layers[i],
+                      i ? p + ".encoder.layer." + std::to_string(i - 1) + ".output.LayerNorm" : std::string()));
   RR_TRY(up_bf16(m, HT(m, "context_text_encoder_linear.weight"), &m->w_li));
   if (c.has_vision) {
     RR_TRY(up_bf16(m, HT(m, "context_vision_projection.model.0.weight"), &m->w_vp0));
@@ -909,7 +1008,8 @@ static int rr_finalize_weights_impl(rr_handle h) {
   RR_TRY(up_f32(m, HT(m, p + ".embeddings.LayerNorm.bias"), &m->ce_emb_b));
   m->ce_layers.resize(c.ce_layers);
   for (int i = 0; i < c.ce_layers; ++i)
-    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i]));
+    RR_TRY(pack_layer(m, p + ".encoder.layer." + std::to_string(i), c.ce_heads, c.ce_hidden, false, &m->ce_layers[i],
+                      i ? p + ".encoder.layer." + std::to_string(i - 1) + ".output.LayerNorm" : std::string()));
   RR_TRY(up_f32(m, HT(m, "reranker.classifier1.weight"), &m->cls1_w));
   RR_TRY(up_f32(m, HT(m, "reranker.classifier1.bias"), &m->cls1_b));
   RR_TRY(up_f32(m, HT(m, "reranker.classifier2.weight"), &m->cls2_w));
@@ -1093,9 +1193,10 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
                             c.type_vocab, w.h32, w.h16, m->dt, st));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
-    for (int l = 0; l < c.layers; ++l)
-      RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs,
-                       m->debug && l == c.layers - 1));
+    bool folded = false;
+    for (int l = 0; l < c.layers; ++l)                    // the last layer's normalised rows feed the 768 -> 128 projection
+      RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs, folded,
+                       l == c.layers - 1, m->debug));
   }
   if (m->debug) {
     const size_t el = (size_t)R * Hd;
@@ -1411,6 +1512,7 @@ static int rr_get_profile_impl(rr_handle h, rr_profile* out, int reset) {
 int rr_set_tuning(const char* key, int value) {
   if (!key) return RR_ERR_BAD_ARG;
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
+  if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);
@@ -1474,6 +1576,33 @@ static int rr_op_gemm_ln_resid_f32_impl(const uint16_t* A, const uint16_t* W, co
   if (!A || !W || !out || !x || !stats || !gamma || !beta) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_gemm_ln(A, Kd, W, Kd, bias, x, N, stats, gamma, beta, out, N, M, N, Kd, EPI_BIAS_RESID_F32, g_op_dt,
                                    (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+/* The two halves of the folded LayerNorm, stand-alone for the operator tests. */
+static int rr_op_gemm_resid_lnprep_impl(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N,
+                                        int Kd, float eps, float* out_f32, uint16_t* x16_out, float* stats_out,
+                                        float* part_scratch, void* hip_stream) {
+  if (!A || !W || !resid || !out_f32 || !x16_out || !stats_out || !part_scratch) return RR_ERR_BAD_ARG;
+  GemmFold f;
+  f.x16 = x16_out;
+  f.ldx = N;
+  f.part = part_scratch;
+  f.nparts = (N + 127) / 128;
+  hipError_t e = rr_launch_gemm_fold(A, Kd, W, Kd, bias, resid, N, nullptr, nullptr, nullptr, f, out_f32, N, M, N, Kd,
+                                     EPI_BIAS_RESID_F32, g_op_dt, (hipStream_t)hip_stream);
+  if (e == hipSuccess) e = rr_launch_ln_finalize(part_scratch, f.nparts, N, eps, M, stats_out, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+static int rr_op_gemm_lnfold_impl(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum,
+                                  const float* stats, int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {
+  if (!A_raw || !W_folded || !csum || !stats || !out) return RR_ERR_BAD_ARG;
+  if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
+  GemmFold f;
+  f.in_stats = stats;
+  f.csum = csum;
+  const int epi_map[3] = {EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32};
+  hipError_t e = rr_launch_gemm_fold(A_raw, Kd, W_folded, Kd, dvec, nullptr, 0, nullptr, nullptr, nullptr, f, out, N, M, N, Kd,
+                                     epi_map[epilogue], g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 static int rr_op_layernorm_stats_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
@@ -1553,6 +1682,14 @@ int rr_op_layernorm_stats(const float* x, const float* gamma, const float* beta,
 }
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, float* out_f32, uint16_t* out_bf16, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_layernorm_impl(x, gamma, beta, eps, rows, cols, out_f32, out_bf16, hip_stream); });
+}
+int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N, int Kd,
+                            float eps, float* out_f32, uint16_t* x16_out, float* stats_out, float* part_scratch, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_resid_lnprep_impl(A, W, bias, resid, M, N, Kd, eps, out_f32, x16_out, stats_out, part_scratch, hip_stream); });
+}
+int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
+                      int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_lnfold_impl(A_raw, W_folded, dvec, csum, stats, M, N, Kd, epilogue, out, hip_stream); });
 }
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_reserve_impl(h, n_pairs, n_queries, len_a, len_b, with_fusion, hip_stream); });

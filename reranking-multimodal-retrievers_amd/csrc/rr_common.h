@@ -120,6 +120,28 @@ hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
                           int epilogue, int dt, hipStream_t st);
 
+// LayerNorm folded into the consumer GEMM (gemm_bf16.hip "LnResid"): producer outputs of a residual GEMM (`x16` 16-bit copy
+// of the fp32 result rows, row stride ldx; `part` [M][nparts] per-128-column-group (mean, sum of squared deviations),
+// nparts = ceil(N / 128)) and/or consumer inputs (`in_stats` [M] (mean, rstd) of the raw A rows, `csum` [N] column sums
+// of the gamma-folded weight; `bias` then holds d = W beta + b).
+struct GemmFold {
+  bf16_t* x16 = nullptr;
+  int ldx = 0;
+  float* part = nullptr;
+  int nparts = 0;
+  const float* in_stats = nullptr;
+  const float* csum = nullptr;
+};
+hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                             int ldr, const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* C, int ldc,
+                             int M, int N, int Kd, int epilogue, int dt, hipStream_t st);
+hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                               int ldr, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                               const GemmFold& fold, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
+                               hipStream_t st);
+// (mean, sum of squared deviations) per 128-column group -> (mean, rstd) per row (Chan's pairwise merge, fp32)
+hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st);
+
 // Multi-head attention, head dim 64.  q rows: q + (bq*Tq + t)*q_stride + head*64, where
 // bq = (b + q_batch_off) / q_batch_div;  k,v rows: (b*Tk + t)*kv_stride + head*64;  key_bias [B,Tk] f32 additive
 // (0 valid, -1e30 masked) or null;  out rows: (b*Tq + t)*out_stride + head*64 (bf16).

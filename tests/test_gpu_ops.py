@@ -504,3 +504,53 @@ def test_gemm_operand_beyond_4_gib(lib, variant):
         err = (out[rows].float() - ref).abs()
         assert torch.isfinite(out[rows].float()).all()
         assert (err <= 1.2e-2 * (1 + ref.abs())).all(), f"rows {r0}: max err {err.max().item()}"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (2000, 768, 3072), (70_000, 768, 768), (1500, 1024, 1024), (77, 128, 256)])
+def test_folded_layernorm_halves(lib, M, N, K):
+    """Producer: residual GEMM that also emits the 16-bit rows and (mean, rstd); consumer: GEMM on the raw rows with the
+    LayerNorm applied to the accumulators.  Small shapes run the 128x128 kernel, 70 000 x 768 the persistent ring."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = (torch.randn(M, N, generator=g) * 2 + 0.7).cuda()                     # rows with a mean
+    out = torch.empty(M, N, device="cuda")
+    x16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    stats = torch.empty(M, 2, device="cuda")
+    part = torch.empty(M, (N + 127) // 128, 2, device="cuda")
+    eps = 1e-12
+    assert lib.rr_op_gemm_resid_lnprep(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), M, N, K, eps, out.data_ptr(),
+                                       x16.data_ptr(), stats.data_ptr(), part.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + b + R
+    assert torch.allclose(out, ref, atol=5e-4, rtol=1e-4)
+    assert torch.equal(x16, out.bfloat16())                                   # the very same values, rounded once
+    mean, var = out.double().mean(1), out.double().var(1, unbiased=False)
+    assert torch.allclose(stats[:, 0].double(), mean, atol=2e-6, rtol=1e-6)
+    assert torch.allclose(stats[:, 1].double(), 1 / torch.sqrt(var + eps), rtol=2e-6)
+    # consumer: LayerNorm(out) W2^T + b2 from the raw 16-bit rows
+    N2 = 256
+    gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.05 * torch.randn(N, generator=g)).cuda()
+    W2 = (torch.randn(N2, N, generator=g) * 0.03).cuda()
+    b2 = torch.randn(N2, generator=g).cuda()
+    Wf = (W2 * gamma[None, :]).bfloat16()
+    csum = Wf.double().sum(1).float()
+    dvec = (W2.double() @ beta.double()).float() + b2
+    for epi, dtype in ((0, torch.bfloat16), (1, torch.bfloat16), (2, torch.float32)):
+        o2 = torch.empty(M, N2, device="cuda", dtype=dtype)
+        assert lib.rr_op_gemm_lnfold(x16.data_ptr(), Wf.data_ptr(), dvec.data_ptr(), csum.data_ptr(), stats.data_ptr(), M, N2, N,
+                                     epi, o2.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        # exact arithmetic on the same operands: rstd * (x16 Wf^T - mean * csum) + d
+        want = stats[:, 1:2] * (x16.float() @ Wf.float().t() - stats[:, 0:1] * csum[None, :]) + dvec
+        if epi == 1:
+            want = _gelu(want)
+        tol = 3e-4 if epi == 2 else 1.2e-2
+        err = (o2.float() - want).abs()
+        assert (err <= tol * (1 + want.abs())).all(), f"epi {epi}: max err {err.max().item()}"
+        # and it IS the LayerNorm-then-Linear of the fp32 rows, up to the 16-bit operand rounding
+        ln = torch.nn.functional.layer_norm(out, (N,), gamma, beta, eps) @ W2.t() + b2
+        if epi == 1:
+            ln = _gelu(ln)
+        assert (o2.float() - ln).abs().max().item() < 0.06
