@@ -71,6 +71,8 @@ def parse_args(argv=None):
                          "residual stream, LayerNorm, softmax stay fp32).  bf16 (what the reference's autocast uses) drifts "
                          "2e-3..1e-2 from fp32 in ANY implementation, the reference's own included (tests/golden/autocast.npz)")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra timing of the other operand type (N=1 only)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
+                    help="process-wide A/B switch of the library (rr_set_tuning), e.g. --tuning ln_fold=0; diagnostic")
     a = ap.parse_args(argv)
     if a.encoder == "bert-large":
         a.workload = "c5"
@@ -239,6 +241,9 @@ def main():
                              compute_dtype=args.compute_dtype, **shape)
     if args.fp8:
         arch["fp8"] = 1
+    for kv in args.tuning:
+        k, v = kv.split("=")
+        assert rmr_amd._lib.load().rr_set_tuning(k.encode(), int(v)) == 0, kv
     sd = rmr_amd.synthetic_state_dict(arch, seed=0, hf_init=True)
     eng = rmr_amd.RerankEngine(arch, dev)
     eng.load_state_dict(sd)

@@ -116,11 +116,27 @@ struct LnResid {
   const float2* in_stats;
   const float* csum;
 };
-// sum over aligned groups of 32 consecutive lanes (= one 128-column group of a row in the staged epilogues)
+// Sum over aligned groups of 32 consecutive lanes, broadcast to every lane of the group, on the DPP data path (VALU
+// operand modifiers: no LDS-crossbar ds_bpermute; 80 of those per pass cost the residual epilogue +24 %): a 16-lane row
+// scan by row_shr 1/2/4/8 (lane 15 of a row then holds the row total), row_bcast:15 adds row 0's total into row 1 and
+// row 2's into row 3, and the two group totals (lanes 31 and 63) come back through v_readlane.
+__device__ __forceinline__ float dpp_f(float old, float v, int ctrl, int row_mask, bool bound) {
+  return __builtin_bit_cast(float, ctrl == 0x111 ? __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)
+                                   : ctrl == 0x112 ? __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true)
+                                   : ctrl == 0x114 ? __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)
+                                   : ctrl == 0x118 ? __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)
+                                                   : __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+}
 __device__ __forceinline__ float group32_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f(0.f, v, 0x111, 0xf, true);      // row_shr:1 (lanes shifted in from outside the row read 0)
+  v += dpp_f(0.f, v, 0x112, 0xf, true);      // row_shr:2
+  v += dpp_f(0.f, v, 0x114, 0xf, true);      // row_shr:4
+  v += dpp_f(0.f, v, 0x118, 0xf, true);      // row_shr:8  -> lane 15 of every row: the row's total
+  v += dpp_f(0.f, v, 0x142, 0xa, false);     // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63: the group totals
+  const int vi = __builtin_bit_cast(int, v);
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
+  return (threadIdx.x & 32) ? hi : lo;
 }
 // Producer side of the folded LayerNorm for one 16-byte chunk (4 consecutive columns gcol..gcol+3 of row gm) of the
 // staged fp32 epilogue; lanes of an aligned group of 32 hold the 32 chunks of one 128-column group of ONE row.  Every
@@ -129,9 +145,10 @@ template <int DT>
 __device__ __forceinline__ void fold_emit(const LnResid& ln, float4 f, bool valid, int gm, int gcol, int N) {
   if (valid) *(uint2*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint2(pack2<DT>(f.x, f.y), pack2<DT>(f.z, f.w));
   const int grp = gcol >> 7;
-  const float cnt = (float)min(128, N - (grp << 7));                 // columns of this group inside the matrix
+  // columns of this group inside the matrix: 128 (reciprocal exact) except in a last, partial group
+  const float rcnt = __builtin_amdgcn_rcpf((float)min(128, N - (grp << 7)));
   const float s = valid ? (f.x + f.y) + (f.z + f.w) : 0.f;
-  const float m = group32_sum(s) / cnt;
+  const float m = group32_sum(s) * rcnt;
   const float a = f.x - m, b = f.y - m, c = f.z - m, d = f.w - m;
   const float q = valid ? (a * a + b * b) + (c * c + d * d) : 0.f;
   const float m2 = group32_sum(q);

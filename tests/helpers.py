@@ -68,7 +68,7 @@ def load_fullsize(name):
     cfg = O.OracleConfig(**kw)
     cfg.loss_fn = "BCE"
     vision, S, pool = bool(z["vision"]), int(z["S"]), int(z["pool"])
-    w = O.make_weights(cfg, seed=0, vision=vision, gain=float(z["gain"]))
+    w = O.make_weights(cfg, seed=0, vision=vision, gain=float(z["gain"]) if "gain" in z.files else 1.0)
     qs = []
     for qi in range(int(z["nq"])):
         seed = int(z[f"q{qi}.seed"])

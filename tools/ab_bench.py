@@ -11,7 +11,7 @@ from rmr_amd.synthetic import image_features, pair_batch
 
 key, vals = sys.argv[1], [int(v) for v in sys.argv[2:]]
 lib = _lib.load()
-arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750, loss_fn="BCE"))
+arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750, loss_fn="BCE"), compute_dtype=os.environ.get("RR_DTYPE", "fp16"))
 eng = rmr_amd.RerankEngine(arch)
 eng.load_state_dict(rmr_amd.synthetic_state_dict(arch, 0, True))
 Bq, K, S = 8, 100, 512
