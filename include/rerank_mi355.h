@@ -305,10 +305,14 @@ int rr_op_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v
 /* e4m3 (OCP fp8) GEMM on the block-scaled matrix core (v_mfma_scale_f32_16x16x128_f8f6f4, block scales 2^0):
  * out = epi(scale * A8[M,K] . W8[N,K]^T + bias), A8/W8 row-major e4m3 bytes, scale = the product of the two per-tensor
  * dequantisation scales, epilogue 0 = bf16 out, 1 = bf16(erf-GELU), 2 = f32 out.  K % 128 == 0, N % 4 == 0.
- * Building block for BASELINE configs[4] (bert-large with fp8 GEMMs); the model forward does not
- * use it yet. */
+ * Per-tensor-scale form (BASELINE configs[4]); the forward uses rr_op_gemm_fp8_rc's scaling. */
 int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, int M, int N, int K, int epilogue,
                    void* out, void* hip_stream);
+/* The form the model forward uses: out = epi(row_scale[m] * col_scale[n] * (A8 . W8^T) + bias), activations quantised per row
+ * (rr_op_layernorm_q8), weights per output channel; either scale vector may be NULL (= 1).  Large problems run the
+ * persistent ring on v_mfma_scale_f32_32x32x64_f8f6f4, small ones the two-stage kernel. */
+int rr_op_gemm_fp8_rc(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
+                      int M, int N, int K, int epilogue, void* out, void* hip_stream);
 /* Per-tensor e4m3 quantisation for rr_op_gemm_fp8: out[i] = e4m3(clamp(x[i] / scale, +-448)), round to nearest even;
  * x holds n (a multiple of 8) f32 values (x_is_f32 != 0) or bf16 values.  rr_op_amax: *out_dev (device float) = max |x|
  * (exact and order-independent), from which the caller derives scale = amax / 448. */

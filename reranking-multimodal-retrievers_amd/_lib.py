@@ -83,6 +83,7 @@ _SIGS = {
     "rr_op_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rr_op_amax": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rr_op_gemm_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rr_op_gemm_fp8_rc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rr_set_attn_stamps": (C.c_int, [_P]),
     "rr_tok_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

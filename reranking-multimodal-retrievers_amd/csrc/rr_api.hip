@@ -32,7 +32,8 @@ hipError_t rr_launch_layernorm_stats(const float*, const float*, const float*, f
                                      int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
-hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, void*, int, int, int, int, int, hipStream_t);
+hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, const float*, const float*, void*, int,
+                              int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_quant_e4m3(const void*, int, float, uint8_t*, size_t, hipStream_t);
 hipError_t rr_launch_amax(const void*, int, size_t, float*, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -1539,10 +1540,18 @@ static int rr_op_gemm_fp8_impl(const uint8_t* A8, const uint8_t* W8, const float
                    void* out, void* hip_stream) {
   if (!A8 || !W8 || !out) return RR_ERR_BAD_ARG;
   if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
-  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, scale, out, N, M, N, K, epilogue, (hipStream_t)hip_stream);
+  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, scale, nullptr, nullptr, out, N, M, N, K, epilogue, g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 
+static int rr_op_gemm_fp8_rc_impl(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale,
+                                  const float* col_scale, int M, int N, int K, int epilogue, void* out, void* hip_stream) {
+  if (!A8 || !W8 || !out) return RR_ERR_BAD_ARG;
+  if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, 1.0f, row_scale, col_scale, out, N, M, N, K, epilogue, g_op_dt,
+                                    (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
 static int rr_op_quantize_fp8_impl(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
   if (!x || !out) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_quant_e4m3(x, x_is_f32, scale, out, n, (hipStream_t)hip_stream);
@@ -1690,6 +1699,10 @@ int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* b
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_gemm_lnfold_impl(A_raw, W_folded, dvec, csum, stats, M, N, Kd, epilogue, out, hip_stream); });
+}
+int rr_op_gemm_fp8_rc(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
+                      int M, int N, int K, int epilogue, void* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_rc_impl(A8, W8, bias, row_scale, col_scale, M, N, K, epilogue, out, hip_stream); });
 }
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_reserve_impl(h, n_pairs, n_queries, len_a, len_b, with_fusion, hip_stream); });

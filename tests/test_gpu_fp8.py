@@ -106,3 +106,36 @@ def test_device_quantised_gemm_end_to_end(lib):
     rel = ((out - ref).norm() / ref.norm()).item()
     print(f"[fp8 gemm, device-quantised] relative Frobenius error vs the 16-bit-operand product: {rel:.3e}")
     assert rel < 0.05
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(33_000, 1024, 128, 0), (33_000, 1024, 256, 1), (33_100, 1024, 1024, 0),
+                                       (66_000, 768, 768 + 128, 1), (300, 384, 256, 2), (517, 1024, 384, 0)])
+def test_gemm_fp8_row_and_channel_scales(lib, M, N, K, epi):
+    """rr_op_gemm_fp8_rc: per-row activation scales x per-channel weight scales.  M >= 33 000 at N = 1024 is 516 tiles of
+    256x256: the persistent ring on the 32x32x64 MFMA, with one, two and many K-tiles (prologue / tail / steady-state
+    paths) and a partial last row tile; the small shapes run the two-stage kernel."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g) * (0.2 + 3.0 * torch.rand(M, 1, device="cuda", generator=g))
+    w = torch.randn(N, K, device="cuda", generator=g) * (0.01 + 0.08 * torch.rand(N, 1, device="cuda", generator=g))
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    sa = a.abs().amax(1) / 448.0
+    sw = w.abs().amax(1) / 448.0
+    a8 = (a / sa[:, None]).to(torch.float8_e4m3fn)
+    w8 = (w / sw[:, None]).to(torch.float8_e4m3fn)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32 if epi == 2 else torch.bfloat16, device="cuda")
+    rc = lib.rr_op_gemm_fp8_rc(a8.view(torch.uint8).data_ptr(), w8.view(torch.uint8).data_ptr(), bias.data_ptr(),
+                               sa.data_ptr(), sw.data_ptr(), M, N, K, epi, out.data_ptr(), _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    for r0 in sorted({0, max(0, M // 2 - 150), max(0, M - 300)}):        # row blocks at the start, the middle and the partial last tile
+        rows = slice(r0, min(M, r0 + 300))
+        af, wf = a8[rows].float(), w8.float()
+        ref = (af @ wf.T) * sa[rows, None] * sw[None, :] + bias
+        mag = (af.abs() @ wf.abs().T) * sa[rows, None] * sw[None, :] + bias.abs()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        got = out[rows].float()
+        assert torch.isfinite(got).all()
+        tol = 1e-4 * mag + (0 if epi == 2 else 2.0 ** -8 * ref.abs()) + 1e-6
+        bad = (got - ref).abs() > tol
+        assert not bad.any(), f"rows {r0}: {int(bad.sum())} beyond tolerance, max |d| {(got - ref).abs().max().item():.3e}"
