@@ -336,6 +336,14 @@ def main():
                                "avg_launch_gflop": g["flops"] / max(1, g["launches"]) / 1e9,
                                "note": "live: per-launch HIP events on the work stream INSIDE the timed region, rank 0 "
                                        "(they cost ~1 % of the step; --no-profile removes them)"}
+            g8 = prof.get("gemm_fp8")
+            if g8 and g8["launches"]:
+                a8 = g8["flops"] / (g8["ms"] * 1e-3) / 1e12
+                res["roofline_fp8"] = {"bound": "mfma", "kernel": "gemm_kernel_hp8 (e4m3 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4, persistent "
+                                       "half-tile LDS ring, per-row x per-channel scales; the QKV and FFN-up launches of the step)",
+                                       "achieved": a8, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": a8 / PEAK_FP8_TFLOPS,
+                                       "launches": g8["launches"], "avg_launch_ms": g8["ms"] / g8["launches"],
+                                       "algorithmic_gb_per_launch": g8["bytes"] / g8["launches"] / 1e9, "traffic": None}
             res["archived_pmc"] = apm
             tot = sum(v["ms"] for v in prof.values())
             res["kernel_time_share"] = {k: (v["ms"] / tot if tot else 0.0) for k, v in prof.items()}

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RR_ABI_VERSION 1
+#define RR_ABI_VERSION 2
 
 typedef enum rr_status {
   RR_OK = 0,
@@ -90,6 +90,11 @@ typedef struct rr_config {
      Defaults of FLMRVisionConfig (configuration_flmr.py:90-104): 12 layers, 12 heads, 3072, 224, 32; hidden =
      vision_hidden, n_patches must equal (vit_image_size / vit_patch_size)^2, head dim 64. */
   int32_t vit_layers, vit_heads, vit_intermediate, vit_image_size, vit_patch_size;
+  int32_t fp8;                /* 1 = BASELINE configs[4] mode: the QKV (layers >= 1 of a stack) and FFN-up GEMMs of the text and
+                                 cross encoder take e4m3 operands on the block-scaled matrix core — activations quantised per row
+                                 by the LayerNorm that produces them, weights per output channel at rr_finalize_weights —
+                                 while attention and the GEMMs feeding the residual stream stay in compute_dtype.  Logit drift
+                                 is reported separately (north_star's 1e-3 is a 16-bit figure); needs hidden % 128 == 0. */
 } rr_config;
 
 /* reranker families */
@@ -105,7 +110,8 @@ typedef struct rr_model* rr_handle;
 /* Per-kernel-class device time accumulated while profiling is on (rr_set_profiling). */
 typedef enum rr_kernel_class {
   RR_K_GEMM = 0, RR_K_ATTENTION = 1, RR_K_LAYERNORM = 2, RR_K_EMBED = 3, RR_K_TAIL = 4, RR_K_HEAD = 5,
-  RR_K_COUNT = 6
+  RR_K_GEMM_FP8 = 6,          /* the e4m3 GEMM launches of rr_config.fp8 (priced against the fp8 matrix-core peak) */
+  RR_K_COUNT = 7
 } rr_kernel_class;
 
 typedef struct rr_profile {
@@ -329,6 +335,12 @@ int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* b
                             float eps, float* out_f32, uint16_t* x16_out, float* stats_out, float* part_scratch, void* hip_stream);
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream);
+/* LayerNorm whose output is an fp8 GEMM operand: out8[row] = e4m3(LN(x[row]) / row_scale[row]), row_scale = row amax / 448,
+ * stats (may be NULL) = (mean, rstd).  rr_util_quantize_rows_e4m3 is the HOST routine the weight packer uses (per output
+ * channel = per row of W [rows, cols]): usable without a GPU. */
+int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, uint8_t* out8,
+                       float* row_scale, float* stats, void* hip_stream);
+int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host);
 int rr_set_gemm_variant(int variant);
 int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */

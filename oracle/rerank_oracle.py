@@ -155,27 +155,47 @@ _MHA = [multi_head_attention]
 
 
 _FOLD = [False]
+_FP8 = [False]
+
+
+def q8_rows(x: Tensor) -> Tensor:
+    """Per-row e4m3 quantise-dequantise (scale = row amax / 448, round to nearest even): the device's layernorm_q8_kernel
+    for activations and the weight packer (host_quantize_rows) for output channels."""
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    return (x * (1.0 / s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s
+
+
+def linear_fp8(x: Tensor, w: Dict[str, Tensor], name: str) -> Tensor:
+    """y = q8_rows(x) q8_rows(W)^T + b: the e4m3 GEMMs of rr_config.fp8 (exact products, fp32 accumulation)."""
+    y = q8_rows(x) @ q8_rows(w[name + ".weight"]).t()
+    b = w.get(name + ".bias")
+    return y if b is None else y + b
 
 
 class device_rounding:
     """`with device_rounding(dtype) as mm:` — run the oracle with the device's 16-bit rounding points
-    (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16").  `fold` (default: as the device):
+    (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16").  `fp8`: rr_config.fp8 — in the encoder
+    stacks the QKV GEMMs of layers >= 1 and every FFN-up GEMM take per-row e4m3 operands (linear_fp8), the LayerNorm
+    kernels are unfolded.  `fold` (default: as the device):
     the encoder stacks (`encoder_stack`) run with LayerNorm folded into the consumer GEMMs, i.e. the 16-bit operand
     of QKV / FFN-up is the RAW pre-LayerNorm row and the normalisation happens on the fp32 accumulators."""
 
-    def __init__(self, dtype=torch.bfloat16, fold: bool = True):
-        self.dtype, self.fold = dtype, fold
+    def __init__(self, dtype=torch.bfloat16, fold: bool = True, fp8: bool = False):
+        self.dtype, self.fold, self.fp8 = dtype, fold and not fp8, fp8
 
     def __enter__(self):
         _MHA.append(multi_head_attention_bf16)
         _RDT.append(self.dtype)
         _FOLD.append(self.fold)
+        _FP8.append(self.fp8)
         return mm_bf16
 
     def __exit__(self, *a):
         _MHA.pop()
         _RDT.pop()
         _FOLD.pop()
+        _FP8.pop()
         return False
 
 
@@ -200,6 +220,20 @@ def encoder_stack(h: Tensor, w: Dict[str, Tensor], prefix: str, n_layers: int, h
     rounding points) = a loop over bert_layer.  Under device_rounding(fold=True) it mirrors the device's folded dataflow:
     layer 0's QKV takes the normalised embedding rows; every FFN-up and every later QKV takes the raw rows of the
     LayerNorm's input with the LayerNorm applied after the GEMM; residuals are the exact fp32 LayerNorm values."""
+    if _FP8[-1] and mm is not None:
+        for i in range(n_layers):
+            p = f"{prefix}.{i}"
+            if i == 0:
+                q, k, v = (linear(h, w, p + ".attention.self." + n, mm) for n in ("query", "key", "value"))
+            else:
+                q, k, v = (linear_fp8(h, w, p + ".attention.self." + n) for n in ("query", "key", "value"))
+            ctx = _MHA[-1](q, k, v, heads, add_mask)
+            a = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + h, w, p + ".attention.output.LayerNorm", eps)
+            inter = gelu_erf(linear_fp8(a, w, p + ".intermediate.dense"))
+            h = layer_norm(linear(inter, w, p + ".output.dense", mm) + a, w, p + ".output.LayerNorm", eps)
+            if taps is not None:
+                taps[f"{tap_name}{i}"] = h
+        return h
     if not (_FOLD[-1] and mm is not None):
         for i in range(n_layers):
             h = bert_layer(h, w, f"{prefix}.{i}", heads, eps, add_mask, mm=mm)

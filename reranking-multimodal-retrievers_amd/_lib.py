@@ -13,14 +13,14 @@ import torch  # noqa: F401  (must be imported first: the process-wide HIP runtim
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librerank_mi355.so")
 
-RR_ABI_VERSION = 1
+RR_ABI_VERSION = 2
 RR_OK, RR_ERR_BAD_ARG, RR_ERR_BAD_SHAPE, RR_ERR_BAD_DTYPE, RR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 RR_ERR_HIP, RR_ERR_OOM, RR_ERR_MISSING_WEIGHT, RR_ERR_NO_DEVICE = -5, -6, -7, -8
 RR_F32, RR_BF16, RR_F16 = 0, 1, 2
 LOSS_KINDS = {"BCE": 0, "2H_BCE": 1, "negative_sampling": 2}
 COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
 MODEL_KINDS = {"full_context": 0, "interaction": 1, "mores": 2}
-KERNEL_CLASSES = ["gemm", "attention", "layernorm", "embed", "tail", "head"]
+KERNEL_CLASSES = ["gemm", "attention", "layernorm", "embed", "tail", "head", "gemm_fp8"]
 
 
 class RRConfig(C.Structure):
@@ -32,12 +32,13 @@ class RRConfig(C.Structure):
                                          "cross_attn_len", "loss_kind")] + \
                [("pos_weight", C.c_float), ("device", C.c_int32), ("compute_dtype", C.c_int32),
                 ("model_kind", C.c_int32), ("vit_layers", C.c_int32), ("vit_heads", C.c_int32),
-                ("vit_intermediate", C.c_int32), ("vit_image_size", C.c_int32), ("vit_patch_size", C.c_int32)]
+                ("vit_intermediate", C.c_int32), ("vit_image_size", C.c_int32), ("vit_patch_size", C.c_int32),
+                ("fp8", C.c_int32)]
 
 
 class RRProfile(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("flops", C.c_double * 6),
-                ("bytes", C.c_double * 6)]
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7), ("flops", C.c_double * 7),
+                ("bytes", C.c_double * 7)]
 
 
 # exceptions mirror the reference's Python error behaviour (include/rerank_mi355.h rr_status comments)
@@ -84,6 +85,8 @@ _SIGS = {
     "rr_op_amax": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rr_op_gemm_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rr_op_gemm_fp8_rc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rr_op_layernorm_q8": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "rr_util_quantize_rows_e4m3": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rr_set_attn_stamps": (C.c_int, [_P]),
     "rr_tok_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

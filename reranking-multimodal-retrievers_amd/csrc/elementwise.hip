@@ -89,6 +89,56 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
   stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / n + eps));
 }
 
+// ---- LayerNorm whose output is the e4m3 operand of an fp8 GEMM (BASELINE configs[4]): y = LN(x) in fp32, one scale per
+// ROW (row amax / 448: the whole e4m3 range is used whatever the row's magnitude; no calibration state), y / scale rounded
+// to nearest even by v_cvt_pk_fp8_f32 (OCP e4m3fn on gfx950).  Also leaves (mean, rstd) for the residual epilogue's ln_apply.
+// 5 bytes per element instead of 6.  A zero row gets scale 1 (all-zero codes).
+__global__ __launch_bounds__(256) void layernorm_q8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int rows, int cols,
+                                                           uint8_t* __restrict__ o8, float* __restrict__ row_scale,
+                                                           float2* __restrict__ stats_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = cols >> 2;
+  float4 v[MAX_V4];
+  const float4* xr = (const float4*)(x + (size_t)row * cols);
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) v[i] = (lane + 64 * i < n4) ? xr[lane + 64 * i] : make_float4(0, 0, 0, 0);
+  const RowStats st = row_stats(v, n4, lane, cols, eps);
+  if (stats_out && lane == 0) stats_out[row] = make_float2(st.mean, st.rstd);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float4 g = ((const float4*)gamma)[c4], b = ((const float4*)beta)[c4];
+      v[i].x = (v[i].x - st.mean) * st.rstd * g.x + b.x;
+      v[i].y = (v[i].y - st.mean) * st.rstd * g.y + b.y;
+      v[i].z = (v[i].z - st.mean) * st.rstd * g.z + b.z;
+      v[i].w = (v[i].w - st.mean) * st.rstd * g.w + b.w;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    }
+  }
+  amax = wave_max(amax);
+  const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / scale;
+  if (lane == 0) row_scale[row] = scale;
+  uint32_t* orow = (uint32_t*)(o8 + (size_t)row * cols);
+#pragma unroll
+  for (int i = 0; i < MAX_V4; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < n4) {
+      const float a = __builtin_amdgcn_fmed3f(v[i].x * inv, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(v[i].y * inv, -448.f, 448.f);
+      const float c = __builtin_amdgcn_fmed3f(v[i].z * inv, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(v[i].w * inv, -448.f, 448.f);
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+      orow[c4] = (uint32_t)w;
+    }
+  }
+}
+
 // ---- BertEmbeddings from ids: word[id] + type[tt] + pos[s] -> LN
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                        const float* __restrict__ word, const float* __restrict__ pos,
@@ -412,6 +462,15 @@ hipError_t rr_launch_layernorm_stats(const float* x, const float* gamma, const f
   if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4 || !stats_out) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols,
                      out_f32, out_bf16, dt, (float2*)stats_out);
+  return hipGetLastError();
+}
+
+// LayerNorm -> e4m3 rows + per-row scales (+ (mean, rstd)); cols % 4 == 0
+hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                                  uint8_t* out8, float* row_scale, float* stats_out, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4 || !out8 || !row_scale) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_q8_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, eps, rows, cols, out8,
+                     row_scale, (float2*)stats_out);
   return hipGetLastError();
 }
 

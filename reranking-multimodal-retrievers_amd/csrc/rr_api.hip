@@ -32,8 +32,6 @@ hipError_t rr_launch_layernorm_stats(const float*, const float*, const float*, f
                                      int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
 hipError_t rr_launch_f32_to_bf16(const float*, bf16_t*, size_t, int, hipStream_t);
-hipError_t rr_launch_gemm_fp8(const uint8_t*, int, const uint8_t*, int, const float*, float, const float*, const float*, void*, int,
-                              int, int, int, int, int, hipStream_t);
 hipError_t rr_launch_quant_e4m3(const void*, int, float, uint8_t*, size_t, hipStream_t);
 hipError_t rr_launch_amax(const void*, int, size_t, float*, hipStream_t);
 hipError_t rr_launch_gather_rows(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
@@ -87,6 +85,35 @@ float host_h2f(uint16_t h) {
   return s ? -v : v;
 }
 
+// OCP e4m3fn, round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 produces for |x| <= 448 on gfx950)
+uint8_t host_f2e4m3(float f) {
+  if (f != f) return 0x7f;
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (a >= 448.0f) return sign | 0x7e;
+  if (a < ldexpf(1.0f, -6)) {                                   // subnormal: multiples of 2^-9
+    const int m = (int)nearbyintf(ldexpf(a, 9));                // 0 .. 8 (8 = the smallest normal)
+    return sign | (uint8_t)m;
+  }
+  int e;
+  const float fr = frexpf(a, &e);                               // a = fr * 2^e, fr in [0.5, 1)
+  e -= 1;                                                       // a = (2 fr) * 2^e, 2 fr in [1, 2)
+  int m = (int)nearbyintf((2.0f * fr - 1.0f) * 8.0f);           // 0 .. 8
+  if (m == 8) { m = 0; e += 1; }
+  if (e > 8 || (e == 8 && m > 6)) return sign | 0x7e;
+  return sign | (uint8_t)(((e + 7) << 3) | m);
+}
+// rows of W [rows, cols] -> e4m3 with one scale per row (amax / 448; a zero row gets scale 1)
+void host_quantize_rows(const float* W, size_t rows, size_t cols, uint8_t* out, float* scales) {
+  for (size_t r = 0; r < rows; ++r) {
+    float amax = 0.f;
+    for (size_t k = 0; k < cols; ++k) amax = fmaxf(amax, fabsf(W[r * cols + k]));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+    scales[r] = sc;
+    for (size_t k = 0; k < cols; ++k) out[r * cols + k] = host_f2e4m3(fminf(fmaxf(W[r * cols + k] * inv, -448.0f), 448.0f));
+  }
+}
+
 struct HostTensor {
   std::vector<int64_t> shape;
   std::vector<float> data;
@@ -102,6 +129,9 @@ struct LayerW {
   // layer's attention-output LayerNorm.
   bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
   float *cqkv_f = nullptr, *dqkv_f = nullptr, *c1_f = nullptr, *d1_f = nullptr;
+  // fp8 mode (cfg.fp8): e4m3 weights, one scale per output channel
+  uint8_t *wqkv8 = nullptr, *w1_8 = nullptr;
+  float *sqkv = nullptr, *s1 = nullptr;
   // cross-attention (transformer mapping network only)
   bf16_t *wq_c = nullptr, *wkv_c = nullptr, *wo_c = nullptr;
   float *bq_c = nullptr, *bkv_c = nullptr, *bo_c = nullptr, *lncg = nullptr, *lncb = nullptr;
@@ -410,6 +440,17 @@ int up_folded(rr_model* m, const std::vector<float>& W, const std::vector<float>
   return up_f32(m, d, d_out);
 }
 
+int up_fp8(rr_model* m, const std::vector<float>& W, size_t cols, uint8_t** w_out, float** s_out) {
+  const size_t rows = W.size() / cols;
+  std::vector<uint8_t> q(W.size());
+  std::vector<float> sc(rows);
+  host_quantize_rows(W.data(), rows, cols, q.data(), sc.data());
+  int rc = dev_alloc(m, (void**)w_out, q.size());
+  if (rc) return rc;
+  RR_HIP(m, hipMemcpy(*w_out, q.data(), q.size(), hipMemcpyHostToDevice));
+  return up_f32(m, sc, s_out);
+}
+
 // prev_ln: state_dict prefix of the LayerNorm whose output feeds this layer's QKV ("" = none: first layer of a stack)
 int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross, LayerW* L, const std::string& prev_ln = "") {
   const float qs = 1.0f / sqrtf((float)(Hd / heads));   // 1/sqrt(dh): 0.125 for dh = 64 (exact in bf16)
@@ -433,6 +474,11 @@ int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross,
   }
   RR_TRY(up_bf16(m, HT(m, p + ".intermediate.dense.weight"), &L->w1));
   RR_TRY(up_f32(m, HT(m, p + ".intermediate.dense.bias"), &L->b1));
+  if (!cross && m->cfg.fp8) {
+    RR_TRY(up_fp8(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs),
+                  (size_t)Hd, &L->wqkv8, &L->sqkv));
+    RR_TRY(up_fp8(m, HT(m, p + ".intermediate.dense.weight"), (size_t)Hd, &L->w1_8, &L->s1));
+  }
   if (!cross) {   // plain encoder layers: folded forms for the LayerNorm -> QKV and LayerNorm -> FFN-up seams
     RR_TRY(up_folded(m, HT(m, p + ".intermediate.dense.weight"), HT(m, p + ".intermediate.dense.bias"),
                      HT(m, a + ".output.LayerNorm.weight"), HT(m, a + ".output.LayerNorm.bias"), &L->w1_f, &L->c1_f, &L->d1_f));
@@ -501,7 +547,7 @@ struct Bump {
 };
 
 struct Work {
-  float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask, *lnpart;
+  float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask, *lnpart, *rowscale;
   bf16_t *h16, *qkv, *ctx, *mid, *li16;
   // vision
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
@@ -541,6 +587,7 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   w->stats_a = b.take<float>(Rm * 2);
   w->stats_b = b.take<float>(Rm * 2);
   w->lnpart = b.take<float>(Rm * 2 * ((Hm + 127) / 128));
+  w->rowscale = b.take<float>(Rm);
   w->h16 = b.take<bf16_t>(Rm * Hm);
   w->qkv = b.take<bf16_t>(Rm * 3 * Hm);
   w->ctx = b.take<bf16_t>(Rm * Hm);
@@ -656,18 +703,28 @@ int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded i
 // (attention output, FFN down) write their fp32 rows, the same rows in 16 bits and per-row statistics partials; a
 // rows x 8-byte finalize merges the partials; QKV / FFN-up read the raw 16-bit rows and apply (mean, rstd) in their
 // epilogue: LN(x) W^T + b = rstd (x W'^T - mean c) + d.
+enum OperandKind { OP_NORMALISED = 0, OP_RAW_FOLDED = 1, OP_E4M3 = 2 };   // what w.h16 holds on entry to a layer (see run_layer)
+
+#define RR_GEMM_FP8(m, st, A8, lda, W8, bias, rsc, csc, C, ldc, M, N, K, epi)                                       \
+  RR_RUN(m, st, RR_K_GEMM_FP8, gemm_flops(M, N, K), 1.0 * (M) * (K) + 1.0 * (N) * (K) + 2.0 * (M) * (N) + 4.0 * (M), \
+         rr_launch_gemm_fp8((const uint8_t*)(A8), lda, W8, K, bias, 1.0f, rsc, csc, C, ldc, M, N, K, epi, m->dt, st))
+
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
-              const float* key_bias, Work& w, ResidSrc& rs, bool& folded_in, bool want_h32, bool want_f32,
+              const float* key_bias, Work& w, ResidSrc& rs, int& in_kind, bool want_h32, bool want_f32,
               const float* dense_bias = nullptr, int dense_ld = 0) {
   const int rows = batch * Tseq;
   const int nparts = (Hd + 127) / 128;
-  const bool fold = g_ln_fold && g_ln_lite && L.w1_f && (Hd % 8 == 0);
-  if (folded_in) {
+  const bool fp8 = m->cfg.fp8 && g_ln_lite && L.w1_8 && (Hd % 128 == 0);
+  const bool fold = !fp8 && g_ln_fold && g_ln_lite && L.w1_f && (Hd % 8 == 0);
+  if (in_kind == OP_RAW_FOLDED) {
     if (!L.wqkv_f) return fail(m, RR_ERR_BAD_ARG, "internal: folded operand into a layer without folded QKV weights");
     GemmFold f;
     f.in_stats = rs.stats;
     f.csum = L.cqkv_f;
     RR_GEMM_FOLDED(m, st, w.h16, Hd, L.wqkv_f, L.dqkv_f, f, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16);
+  } else if (in_kind == OP_E4M3) {
+    if (!L.wqkv8) return fail(m, RR_ERR_BAD_ARG, "internal: e4m3 operand into a layer without e4m3 QKV weights");
+    RR_GEMM_FP8(m, st, w.h16, Hd, L.wqkv8, L.bqkv, w.rowscale, L.sqkv, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, 0);
   } else {
     RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   }
@@ -684,7 +741,29 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
            rr_launch_layernorm(w.pre, L.ln2g, L.ln2b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
     rs = r0;
-    folded_in = false;
+    in_kind = OP_NORMALISED;
+    return RR_OK;
+  }
+  if (fp8) {
+    // configs[4]: the two LayerNorm outputs are quantised to e4m3 (one scale per row) by the LayerNorm kernel itself and
+    // feed FFN-up / the next layer's QKV on the block-scaled matrix core; attention output and FFN-down stay 16-bit
+    RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 5.0 * rows * Hd,
+           rr_launch_layernorm_q8(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, (uint8_t*)w.h16, w.rowscale, w.stats_a, st));
+    RR_GEMM_FP8(m, st, w.h16, Hd, L.w1_8, L.b1, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 1);
+    const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
+    RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
+    if (want_h32) {
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
+             rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_f32 ? w.h32 : nullptr, w.h16, w.stats_b,
+                                       m->dt, st));
+      in_kind = OP_NORMALISED;
+    } else {
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 5.0 * rows * Hd,
+             rr_launch_layernorm_q8(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, (uint8_t*)w.h16, w.rowscale, w.stats_b, st));
+      in_kind = OP_E4M3;
+    }
+    rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
     return RR_OK;
   }
   if (fold) {
@@ -705,11 +784,11 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
            rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st));
     rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
-    folded_in = true;
+    in_kind = OP_RAW_FOLDED;
     if (want_h32) {   // last layer of a stack: its consumers (CLS heads, 768->128 projection, debug taps) take normalised rows
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
              rr_launch_layernorm(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_f32 ? w.h32 : nullptr, w.h16, m->dt, st));
-      folded_in = false;
+      in_kind = OP_NORMALISED;
     }
     return RR_OK;
   }
@@ -723,7 +802,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
          rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, (want_h32 && want_f32) ? w.h32 : nullptr, w.h16,
                                    w.stats_b, m->dt, st));
   rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
-  folded_in = false;
+  in_kind = OP_NORMALISED;
   return RR_OK;
 }
 
@@ -773,7 +852,7 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const 
          rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
-    bool folded = false;
+    int folded = OP_NORMALISED;
     for (int l = 0; l < c.ce_layers; ++l)
       RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
                        l == c.ce_layers - 1, true,          // the CLS heads read the fp32 rows of the last layer
@@ -794,6 +873,7 @@ size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, cha
   w->stats_a = b.take<float>(RT * 2);
   w->stats_b = b.take<float>(RT * 2);
   w->lnpart = b.take<float>(RT * 2 * ((Hc + 127) / 128));
+  w->rowscale = b.take<float>(RT);
   w->h16 = b.take<bf16_t>(RT * Hc);
   w->qkv = b.take<bf16_t>(RT * 3 * Hc);
   w->ctx = b.take<bf16_t>(RT * Hc);
@@ -821,7 +901,7 @@ size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, cha
 
 extern "C" {
 
-const char* rr_version(void) { return "librerank_mi355 0.1.0 (gfx950, abi 1)"; }
+const char* rr_version(void) { return "librerank_mi355 0.2.0 (gfx950, abi 2)"; }
 
 const char* rr_status_string(int s) {
   switch (s) {
@@ -882,6 +962,8 @@ static int rr_create_impl(const rr_config* cfg, rr_handle* out) {
   }
   if (hipSetDevice(c.device) != hipSuccess) return RR_ERR_HIP;
   if (c.compute_dtype != 0 && c.compute_dtype != 1) return bad("compute_dtype must be 0 (bf16) or 1 (fp16)");
+  if (c.fp8 != 0 && c.fp8 != 1) return bad("fp8 must be 0 or 1");
+  if (c.fp8 && ((c.hidden % 128) || (c.ce_hidden % 128))) return bad("fp8 mode needs hidden sizes that are multiples of 128");
   if (c.model_kind < 0 || c.model_kind > 2) return bad("model_kind must be 0 (full context), 1 (interaction) or 2 (MORES)");
   rr_model* m = new rr_model();
   m->cfg = c;
@@ -1194,7 +1276,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
                             c.type_vocab, w.h32, w.h16, m->dt, st));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
-    bool folded = false;
+    int folded = OP_NORMALISED;
     for (int l = 0; l < c.layers; ++l)                    // the last layer's normalised rows feed the 768 -> 128 projection
       RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs, folded,
                        l == c.layers - 1, m->debug));
@@ -1552,6 +1634,12 @@ static int rr_op_gemm_fp8_rc_impl(const uint8_t* A8, const uint8_t* W8, const fl
                                     (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
+static int rr_op_layernorm_q8_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                                   uint8_t* out8, float* row_scale, float* stats, void* hip_stream) {
+  if (!x || !gamma || !beta || !out8 || !row_scale) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_layernorm_q8(x, gamma, beta, eps, rows, cols, out8, row_scale, stats, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
 static int rr_op_quantize_fp8_impl(const void* x, int x_is_f32, float scale, uint8_t* out, size_t n, void* hip_stream) {
   if (!x || !out) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_quant_e4m3(x, x_is_f32, scale, out, n, (hipStream_t)hip_stream);
@@ -1703,6 +1791,14 @@ int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const flo
 int rr_op_gemm_fp8_rc(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
                       int M, int N, int K, int epilogue, void* out, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_rc_impl(A8, W8, bias, row_scale, col_scale, M, N, K, epilogue, out, hip_stream); });
+}
+int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, uint8_t* out8,
+                       float* row_scale, float* stats, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_layernorm_q8_impl(x, gamma, beta, eps, rows, cols, out8, row_scale, stats, hip_stream); });
+}
+int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host) {
+  if (!w_host || !out_host || !scales_host || rows <= 0 || cols <= 0) return RR_ERR_BAD_ARG;
+  return guarded(nullptr, [&]() -> int { host_quantize_rows(w_host, (size_t)rows, (size_t)cols, out_host, scales_host); return RR_OK; });
 }
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_reserve_impl(h, n_pairs, n_queries, len_a, len_b, with_fusion, hip_stream); });

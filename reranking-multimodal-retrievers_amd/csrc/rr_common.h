@@ -142,6 +142,13 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
 // (mean, sum of squared deviations) per 128-column group -> (mean, rstd) per row (Chan's pairwise merge, fp32)
 hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st);
 
+// fp8 (csrc/gemm_fp8.hip, elementwise.hip)
+hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* bias, float scale,
+                              const float* row_scale, const float* col_scale, void* C, int ldc, int M, int N, int Kd,
+                              int epilogue, int dt, hipStream_t st);
+hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
+                                  uint8_t* out8, float* row_scale, float* stats_out, hipStream_t st);
+
 // Multi-head attention, head dim 64.  q rows: q + (bq*Tq + t)*q_stride + head*64, where
 // bq = (b + q_batch_off) / q_batch_div;  k,v rows: (b*Tk + t)*kv_stride + head*64;  key_bias [B,Tk] f32 additive
 // (0 valid, -1e30 masked) or null;  out rows: (b*Tq + t)*out_stride + head*64 (bf16).

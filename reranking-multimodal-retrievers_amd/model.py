@@ -211,6 +211,7 @@ class RerankEngine:
         c.model_kind = L.MODEL_KINDS[mk]
         for k, v in VIT_DEFAULTS.items():
             setattr(c, k, int(arch.get(k, v)))
+        c.fp8 = int(bool(arch.get("fp8", 0)))      # BASELINE configs[4]: e4m3 QKV / FFN-up GEMMs (rr_config.fp8)
         c.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         L.check(self.lib.rr_create(C.byref(c), C.byref(h)), None, "rr_create")

@@ -41,8 +41,8 @@ def test_version_and_status_strings(lib):
 def test_config_struct_layout_matches_header():
     from rmr_amd import _lib
     # 8 + 1 + 1 + 12 + 1 + 1 + 7 four-byte fields
-    assert C.sizeof(_lib.RRConfig) == 4 * 31
-    assert C.sizeof(_lib.RRProfile) == 8 * 6 * 4
+    assert C.sizeof(_lib.RRConfig) == 4 * 32     # 31 fields of ABI 1 + fp8 (ABI 2)
+    assert C.sizeof(_lib.RRProfile) == 8 * 7 * 4
 
 
 def test_no_gpu_means_loud_failure(lib):
@@ -52,7 +52,7 @@ def test_no_gpu_means_loud_failure(lib):
     import rmr_amd
     from rmr_amd import _lib
     c = _lib.RRConfig()
-    c.abi_version = 1
+    c.abi_version = _lib.RR_ABI_VERSION
     for k, v in dict(vocab_size=100, hidden=128, layers=1, heads=2, intermediate=256, max_pos=64, type_vocab=2,
                      li_dim=64, ce_hidden=128, ce_layers=1, ce_heads=2, ce_intermediate=256, ce_max_pos=64).items():
         setattr(c, k, v)
@@ -100,3 +100,27 @@ def test_weight_spec_matches_library_required_names():
                                       hf_init=False)
     ref = O.make_weights(O.OracleConfig(layers=1, vocab_size=50), seed=3, vision=True)
     assert all((sd[k] == ref[k]).all() for k in ref) and set(sd) == set(ref)
+
+
+def test_host_row_quantiser_matches_torch_e4m3():
+    """rr_util_quantize_rows_e4m3 (the weight packer of rr_config.fp8; pure host code) against torch.float8_e4m3fn:
+    per-row scale amax / 448, round to nearest even, including subnormal codes, exact zeros and a zero row."""
+    import ctypes as C
+
+    import torch
+    from rmr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(37, 256, generator=g) * torch.logspace(-4, 1, 37)[:, None]
+    W[5] = 0.0
+    W[7, :20] = W[7].abs().max() * torch.logspace(-6, -1, 20)           # deep into the subnormal codes of that row
+    W[9, 3] = 0.0
+    out = torch.empty(37, 256, dtype=torch.uint8)
+    sc = torch.empty(37)
+    assert lib.rr_util_quantize_rows_e4m3(W.data_ptr(), 37, 256, out.data_ptr(), sc.data_ptr()) == 0
+    amax = W.abs().amax(1)
+    want_s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    assert torch.equal(sc, want_s)
+    want = (W * (1.0 / want_s)[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    same = (out == want) | ((out & 0x7f) == 0) & ((want & 0x7f) == 0)     # +0 / -0 both encode zero
+    assert same.all(), f"{int((~same).sum())} codes differ"

@@ -139,3 +139,93 @@ def test_gemm_fp8_row_and_channel_scales(lib, M, N, K, epi):
         tol = 1e-4 * mag + (0 if epi == 2 else 2.0 ** -8 * ref.abs()) + 1e-6
         bad = (got - ref).abs() > tol
         assert not bad.any(), f"rows {r0}: {int(bad.sum())} beyond tolerance, max |d| {(got - ref).abs().max().item():.3e}"
+
+
+def test_layernorm_q8_matches_torch(lib):
+    """LayerNorm -> per-row e4m3 (rr_op_layernorm_q8): scales = row amax / 448 of the fp32 LayerNorm output, codes equal
+    torch's e4m3 rounding of the same values except where a last-bit difference of the fp32 LayerNorm arithmetic sits on a
+    rounding boundary (then they differ by one code step)."""
+    rows, cols = 777, 1024
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(rows, cols, generator=g) * 1.3 + 0.4).cuda()
+    x[3] = 0.0                                                            # zero variance row: LN output = beta
+    gamma, beta = (1 + 0.2 * torch.randn(cols, generator=g)).cuda(), (0.1 * torch.randn(cols, generator=g)).cuda()
+    out = torch.zeros(rows, cols, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(rows, device="cuda")
+    st = torch.zeros(rows, 2, device="cuda")
+    eps = 1e-12
+    assert lib.rr_op_layernorm_q8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, rows, cols, out.data_ptr(), sc.data_ptr(),
+                                  st.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    y = torch.nn.functional.layer_norm(x, (cols,), gamma, beta, eps)
+    want_s = y.abs().amax(1) / 448.0
+    assert torch.allclose(sc, want_s, rtol=3e-6, atol=0)
+    deq = out.view(torch.float8_e4m3fn).float() * sc[:, None]
+    # e4m3 has 3 mantissa bits: |dequantised - y| <= half a code step (2^-4 relative) + the scale's share of the subnormal step
+    assert ((deq - y).abs() <= 0.0626 * y.abs() + sc[:, None] * 2.0 ** -10 + 1e-7).all()
+    want = (y / sc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    frac = (out != want).float().mean().item()
+    assert frac < 2e-3, f"{frac:.2e} of the codes differ from torch's rounding of torch's LayerNorm"
+    assert torch.allclose(st[:, 0], x.mean(1), atol=1e-5) and torch.allclose(st[4:, 1], 1 / torch.sqrt(x[4:].var(1, unbiased=False) + eps), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_fp8_forward_small_model_against_the_oracle_emulation(dt):
+    """rr_config.fp8 on a 3-layer 256-wide model (K = 256: two K-tiles; small problems run the two-stage e4m3 kernel):
+    the device forward against the oracle with the same e4m3 rounding points (device_rounding(fp8=True)), and the drift
+    both have from the fp32 forward."""
+    import rmr_amd
+    from helpers import O, arch_from_cfg
+    cfg = O.OracleConfig(vocab_size=2000, hidden=256, layers=3, heads=4, intermediate=1024, max_pos=64, ce_hidden=256,
+                         ce_heads=4, ce_intermediate=1024, ce_layers=2, ce_max_pos=128, li_dim=64)
+    cfg.loss_fn = "BCE"
+    Bq, K, S = 2, 6, 64
+    w = O.make_weights(cfg, seed=2, vision=False)
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=4)
+    arch = arch_from_cfg(cfg, False, dt)
+    arch["fp8"] = 1
+    eng = rmr_amd.RerankEngine(arch)
+    eng.load_state_dict(w)
+    r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K, want_order=True)
+    torch.cuda.synchronize()
+    got = r["logits"].cpu()
+    with torch.no_grad():
+        ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K).logits.reshape(-1)
+        with O.device_rounding(torch.float16 if dt == "fp16" else torch.bfloat16, fp8=True) as mm:
+            emu = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, mm=mm).logits.reshape(-1)
+        with O.device_rounding(torch.float16 if dt == "fp16" else torch.bfloat16, fold=False) as mm:
+            b16 = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, mm=mm).logits.reshape(-1)
+    d_emu, d_ref, e_ref = (got - emu).abs().max().item(), (got - ref).abs().max().item(), (emu - ref).abs().max().item()
+    print(f"[fp8 small/{dt}] device vs same-rounding oracle {d_emu:.2e}; device vs fp32 {d_ref:.2e}; oracle-fp8 vs fp32 {e_ref:.2e}; "
+          f"16-bit vs fp32 {(b16 - ref).abs().max().item():.2e}")
+    assert torch.isfinite(got).all()
+    assert d_emu <= max(2e-3, 0.5 * e_ref)          # same rounding points: well inside the e4m3 drift itself
+    assert d_ref <= 2.0 * e_ref + 1e-3
+    assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
+
+
+def test_fp8_forward_bert_large_against_the_c5_golden():
+    """BASELINE configs[4]: bert-large, K = 200, S = 512, e4m3 QKV / FFN-up GEMMs.  north_star's 1e-3 is a 16-bit
+    figure; for e4m3 the drift from the committed fp32 stock-HF logits is REPORTED and bounded: absolute, and centred per
+    candidate list (what ranking sees), next to the reference's own bf16-autocast drift on the same inputs."""
+    import rmr_amd
+    from helpers import O, arch_from_cfg, load_fullsize
+    cfg, w, vision, qs = load_fullsize("c5_full")
+    q = qs[0]
+    arch = arch_from_cfg(cfg, vision, "fp16")
+    arch["fp8"] = 1
+    eng = rmr_amd.RerankEngine(arch)
+    eng.load_state_dict(w)
+    K = q["ids"].shape[0]
+    r = eng.forward_ids(q["ids"].cuda(), q["am"].cuda(), q["tt"].cuda(), 1, K, want_order=True)
+    torch.cuda.synchronize()
+    got, ref, ac = r["logits"].cpu(), q["fp32"], q["autocast"]
+    d = got - ref
+    dc = d - d.mean()
+    rho = torch.corrcoef(torch.stack([ref.argsort().argsort().float(), got.argsort().argsort().float()]))[0, 1].item()
+    top5 = len(set(ref.argsort(descending=True)[:5].tolist()) & set(got.argsort(descending=True)[:5].tolist()))
+    print(f"[c5_full/fp8+fp16] K={K}: |dlogit| vs fp32 max {d.abs().max():.3e}, centred {dc.abs().max():.3e}; logit std over the list "
+          f"{ref.std():.3f}; rank correlation {rho:.4f}; top-5 overlap {top5}/5; reference bf16-autocast drift {(ac - ref).abs().max():.3e}")
+    assert torch.isfinite(got).all()
+    assert d.abs().max().item() <= 0.25 and dc.abs().max().item() <= 0.08
+    assert rho >= 0.9
