@@ -115,6 +115,7 @@ struct LnResid {
   int nparts;            // ceil(N / 128)
   const float2* in_stats;
   const float* csum;
+  int flags;             // bit 0: touch the next pass's residual lines a pass ahead (rr_set_tuning "resid_touch")
 };
 // Sum over aligned groups of 32 consecutive lanes, broadcast to every lane of the group, on the DPP data path (VALU
 // operand modifiers: no LDS-crossbar ds_bpermute; 80 of those per pass cost the residual epilogue +24 %): a 16-lane row
@@ -1122,6 +1123,19 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       lg = *(const float4*)(ln.gamma + my_col);
       lb = *(const float4*)(ln.beta + my_col);
     }
+    // The residual rows of a pass are first touched by a register-free LDS-DMA, one 128-byte line per thread (64 rows x
+    // 1 KiB = 512 lines), a pass ahead of the loads that consume them: the loads behind the barrier then find their lines
+    // in the XCD's L2 instead of paying the HBM latency in front of the first add, four times per tile.  The touched
+    // dwords land in the unused tail of the staging region and are never read.
+    auto touch_resid = [&](int pass_) {
+      if (EPI != EPI_BIAS_RESID_F32 || !(ln.flags & 1)) return;
+      if (cm0 + 256 > M || cn0 + 256 > N) return;                   // ragged last tiles: not worth a clamp per lane
+      const float* sb = resid + (size_t)(cm0 + (pass_ >> 1) * 128 + (pass_ & 1) * 64) * ldr + cn0;   // scalar
+      const uint32_t vo = (uint32_t)(((tid >> 3) * ldr + (tid & 7) * 32) * 4);                        // line `tid` of the 64 x 256 block
+      glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+    };
+    static_assert(!F32_OUT || 5 * HALF + ROWS * PITCH + 8 * 256 <= 160 * 1024, "touch area must fit behind the staging image");
+    touch_resid(0);
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1146,6 +1160,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       // the next tile's prefetched half-tiles: confirm MY pieces now, while the only younger vector-memory operations
       // are this epilogue's own loads (none issued yet in this pass) — not after the stores
       if (pass == 0 && has_next) wait_vmcnt<0>();
+      if (pass + 1 < NPASS) touch_resid(pass + 1);
       lds_barrier();
       const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
       // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
@@ -1206,6 +1221,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
+std::atomic<int> g_resid_touch{1};       // rr_set_tuning("resid_touch")
 std::atomic<int> g_variant{-1};          // tuning override (rr_set_gemm_variant / RR_GEMM_VARIANT); -1: shape heuristic
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember per device ordinal where
@@ -1364,6 +1380,10 @@ extern "C" int rr_set_gemm_variant(int v) {
   g_variant.store(v);
   return 0;
 }
+extern "C" int rr_set_resid_touch(int on) {
+  g_resid_touch.store(on != 0);
+  return 0;
+}
 extern "C" int rr_set_gemm_persistent(int on) {
   g_persistent = on != 0;
   return 0;
@@ -1404,7 +1424,7 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
   if ((fold.in_stats != nullptr) != (fold.csum != nullptr)) return hipErrorInvalidValue;
   if (fold.in_stats && (epilogue == EPI_BIAS_RESID_F32)) return hipErrorInvalidValue;
   const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta, fold.x16, fold.ldx, (float2*)fold.part, fold.nparts,
-                   (const float2*)fold.in_stats, fold.csum};
+                   (const float2*)fold.in_stats, fold.csum, g_resid_touch.load()};
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
   if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;

@@ -664,6 +664,7 @@ double gemm_bytes(double M, double N, double K, double out_elt) { return 2.0 * (
          rr_launch_gemm(A, lda, W, K, bias, resid, ldr, C, ldc, M, N, K, epi, m->dt, st))
 
 extern "C" int rr_set_gemm_persistent(int on);
+extern "C" int rr_set_resid_touch(int on);
 extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
@@ -1597,6 +1598,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
+  if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);
   return RR_ERR_BAD_ARG;

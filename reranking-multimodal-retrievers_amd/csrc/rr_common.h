@@ -89,6 +89,21 @@ __device__ __forceinline__ void glds16_so(const void* sbase, uint32_t voff, uint
       : "memory");
 }
 
+// 4 bytes per lane into LDS (wave-uniform destination + lane*4): used as a no-register "touch" that pulls one 128-byte
+// line per lane towards the XCD's L2 ahead of the real loads (the bytes that land in LDS are never read)
+__device__ __forceinline__ void glds4_so(const void* sbase, uint32_t voff, uint32_t lds_dst_wave_base) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst_wave_base)
+      : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
