@@ -918,7 +918,16 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // BEHIND wins the MFMA pipe, so they advance together instead of the older wave racing ahead to idle at the barrier
 #define RR_PRIO(p) __builtin_amdgcn_s_setprio(p);
 
+  // Folded LayerNorm, consumer side: the (mean, rstd) of this tile's 256 rows (2 KiB = 16 lines) are touched by one
+  // register-free LDS-DMA per tile while the main loop runs, so that the epilogue's statistics loads hit L2 (the dwords
+  // land in LDS beyond the ring, [128 KiB, ...), which nothing reads).  Issued BEFORE the tile's ring refills: an
+  // older operation only makes the counted waits of the loop marginally stricter, never weaker.
+  auto touch_stats = [&](int m0_) {
+    if (!ln.in_stats || !(ln.flags & 1) || wave != 0 || m0_ + 256 > M) return;
+    glds4_so(ln.in_stats + m0_, (uint32_t)((lane & 15) * 128), __builtin_amdgcn_readfirstlane(lds_base + 8 * HALF));
+  };
   // ---- first output tile: cold prologue, half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3})
+  touch_stats(m0);
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
   if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
   bool first_tile = true;
@@ -1210,6 +1219,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   if (first_tile) stamp(stamps, 3);
   first_tile = false;
   if (!has_next) break;
+  touch_stats(m0);                                          // (LDS beyond the ring is free again: the staging image is consumed)
   if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) }                 // slots 5, 6 were under the staging image until now
   }   // output tiles
 #undef RR_SETUP_SRC
