@@ -83,7 +83,12 @@ def linear(x: Tensor, w: Dict[str, Tensor], name: str, mm=None) -> Tensor:
     matmul to emulate the device's rounding points; default = fp32."""
     W = w[name + ".weight"]
     b = w.get(name + ".bias")
-    y = (mm(x, W) if mm is not None else x @ W.t())
+    if mm is not None and name.endswith(_QUERY_NAMES):
+        # device: the packed query weight is 16bit(W * log2(e)/sqrt(dh)), its bias b * the same factor (rr_api.hip
+        # pack_layer); dividing back keeps this function's contract (unscaled q) with the device's rounding of W
+        y = mm(x, W * _QSCALE) * (1.0 / _QSCALE)
+    else:
+        y = (mm(x, W) if mm is not None else x @ W.t())
     return y if b is None else y + b
 
 
@@ -123,6 +128,8 @@ def multi_head_attention(q: Tensor, k: Tensor, v: Tensor, heads: int,
 # tests can separate "bf16 operand rounding" (inherent, shared with the reference's bf16-mixed runs)
 # from kernel bugs.
 _RDT = [torch.bfloat16]          # 16-bit operand dtype being emulated (device compute_dtype)
+_QSCALE = math.log2(math.e) / 8.0     # log2(e)/sqrt(dh) at dh = 64 (the only head dimension of the path): folded into Wq
+_QUERY_NAMES = (".query", ".q_proj")
 
 
 def _bf(x: Tensor) -> Tensor:
@@ -137,16 +144,17 @@ def multi_head_attention_bf16(q: Tensor, k: Tensor, v: Tensor, heads: int, add_m
     B, Tq, H = q.shape
     Tk = k.shape[1]
     dh = H // heads
-    q, k, v = _bf(q), _bf(k), _bf(v)
+    # device: Q is stored as 16bit(q * log2(e)/sqrt(dh)), so Q K^T is in the log2 domain and the softmax is base 2
+    q, k, v = _bf(q * (math.log2(math.e) / math.sqrt(dh))), _bf(k), _bf(v)
     qh = q.view(B, Tq, heads, dh).transpose(1, 2)
     kh = k.view(B, Tk, heads, dh).transpose(1, 2)
     vh = v.view(B, Tk, heads, dh).transpose(1, 2)
-    scores = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
-    if add_mask is not None:
-        scores = scores + add_mask
+    scores = qh @ kh.transpose(-1, -2)
+    if add_mask is not None:      # an additive mask (finite in the fusion adjacency) enters the log2 domain scaled as well
+        scores = scores + torch.clamp(add_mask * math.log2(math.e), min=FMIN)
     # device: P = exp2(s - max) is rounded to bf16 for the PV MFMA, the row sum stays fp32
     m = scores.max(dim=-1, keepdim=True).values
-    e = torch.exp(scores - m)
+    e = torch.exp2(scores - m)
     ctx = (_bf(e) @ vh) / e.sum(dim=-1, keepdim=True)
     return ctx.transpose(1, 2).reshape(B, Tq, H)
 
@@ -199,14 +207,15 @@ class device_rounding:
         return False
 
 
-def folded_linear(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, W: Tensor, b: Optional[Tensor]) -> Tensor:
+def folded_linear(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, W: Tensor, b: Optional[Tensor],
+                  wscale: float = 1.0) -> Tensor:
     """Device form of Linear(LayerNorm(x)) with the LayerNorm folded into the GEMM (csrc/gemm_bf16.hip LnResid):
     rstd * (x16 W'^T - mean * c) + d,  W' = 16bit(W * gamma),  c = row sums of W',  d = W beta + b;  mean / variance of the
     fp32 row (the device merges per-128-column (mean, M2) partials: same quantities, fp32)."""
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     rstd = torch.rsqrt(var + eps)
-    Wp = _bf(W * gamma[None, :])
+    Wp = _bf(W * gamma[None, :] * wscale) * (1.0 / wscale)      # wscale: the query weight's log2(e)/sqrt(dh), see linear()
     c = Wp.double().sum(1).float()
     d = (W.double() @ beta.double()).float()
     if b is not None:
@@ -246,7 +255,8 @@ def encoder_stack(h: Tensor, w: Dict[str, Tensor], prefix: str, n_layers: int, h
         if pre is None:
             q, k, v = (linear(h, w, p + ".attention.self." + n, mm) for n in ("query", "key", "value"))
         else:
-            q, k, v = (folded_linear(pre, g, b, eps, w[p + f".attention.self.{n}.weight"], w[p + f".attention.self.{n}.bias"])
+            q, k, v = (folded_linear(pre, g, b, eps, w[p + f".attention.self.{n}.weight"], w[p + f".attention.self.{n}.bias"],
+                                     _QSCALE if n == "query" else 1.0)
                        for n in ("query", "key", "value"))
         ctx = _MHA[-1](q, k, v, heads, add_mask)
         pre1 = linear(ctx, w, p + ".attention.output.dense", mm) + h

@@ -4,8 +4,9 @@
 // (/root/reference/src/models/flmr/models/flmr/modeling_flmr.py:1622 text encoder;
 //  src/models/rerank/attention_fusion.py:133-144 cross encoder; modeling_flmr.py:640-658 mapping
 //  network self/cross attention) without ever materialising the [N,heads,T,T] score tensor
-// (1.26 GB at c3).  1/sqrt(dh) is folded into Wq at weight-pack time
-// (0.125 is a power of two => bit-exact), so Q arrives pre-scaled.
+// (1.26 GB at c3).  log2(e)/sqrt(dh) is folded into Wq and bq at weight-pack time, so Q arrives
+// pre-scaled and Q K^T is already the argument of the hardware's base-2 exponential: no multiply per score.  Additive
+// biases (-1e30 / -inf per key) need no rescaling; the dense per-(query, key) bias is multiplied by log2(e) when added.
 //
 // Structure: workgroup = 4 waves = 128 query rows of one (pair, head); wave = 32 query rows.
 //   * S^T = K Q^T is issued "swapped" (A-operand = K rows, B-operand = Q rows) with
@@ -34,7 +35,16 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LOG2E = 1.4426950408889634f;   // only the DENSE bias is still scaled in the kernel
+
+// -x rounded to the 16-bit operand type: the fixed reference of a row as an MFMA operand (bits) and as the float it denotes
+template <int DT>
+__device__ __forceinline__ uint32_t ref16(float x, float& back) {
+  const uint32_t u = pack2<DT>(x, 0.f) & 0xffffu;
+  if constexpr (DT == 0) back = __builtin_bit_cast(float, u << 16);
+  else back = (float)__builtin_bit_cast(_Float16, (unsigned short)u);
+  return u;
+}
 constexpr int KT = 64;                     // keys per tile
 constexpr int TILE_BYTES = KT * 64 * 2;    // 8 KiB (K or V tile)
 
@@ -63,7 +73,34 @@ __device__ __forceinline__ const bf16_t* uniform_ptr(const bf16_t* p) {
   return (const bf16_t*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int ATTN_LDS_BYTES = 4 * TILE_BYTES + 2 * KT * 4 + 16;
+// Key bias: a chunk of BIAS_TILES tiles (1024 keys) is resident in LDS with one flag word per tile, loaded by the whole
+// workgroup before the tile loop (and again every 16 tiles for longer sequences): the tile loop itself holds no global load
+// the compiler can see.  With one in it, hipcc's scoreboard — which cannot see the hand-counted LDS-DMA — guarded the load's
+// destination register with s_waitcnt vmcnt(0) right behind the four DMA pieces just issued, i.e. every tile waited for its
+// own prefetch to land (the QK^T section of the timeline: 2330 cycles against 260 of MFMA).
+constexpr int BIAS_TILES = 16;
+constexpr int ATTN_LDS_BYTES = 4 * TILE_BYTES + BIAS_TILES * KT * 4 + BIAS_TILES * 4;   // K/V double buffers, key bias chunk, tile flags
+
+// Load bias chunk c (keys [1024 c, 1024 c + 1024) of sequence b; 0 without a bias, -inf beyond Tk) and its tile flags
+// (bit 0: some key of the tile has a bias, bit 1: no key of the tile is valid).  All 256 threads; two barriers inside; the
+// caller guarantees that no wave still reads the previous chunk.
+__device__ __forceinline__ void load_bias_chunk(float* const b_all, int* const f_all, const float* key_bias, const int b,
+                                                const int Tk, const int c) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < BIAS_TILES * KT / 256; ++j) {
+    const int key = c * (BIAS_TILES * KT) + j * 256 + tid;
+    b_all[j * 256 + tid] = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tile = wave; tile < BIAS_TILES; tile += 4) {
+    const float v = b_all[tile * KT + lane];
+    const unsigned long long any = __ballot(v != 0.f), valid = __ballot(v > -1e29f);
+    if (lane == 0) f_all[tile] = (any != 0ull ? 1 : 0) | (valid == 0ull ? 2 : 0);
+  }
+  __syncthreads();
+}
 
 struct AttnArgs {
   const bf16_t* q; int q_stride, q_batch_div, q_batch_off;
@@ -90,8 +127,10 @@ __device__ __forceinline__ bool block_map(const int bid, const int nqb, const in
 //   FIXED = false: online softmax (running max, O rescaled by exp(m_old - m_new) every tile) — exact for any input.
 //   FIXED = true : the exponentials are taken against a FIXED per-row reference (the row maximum of the first tile that
 //     holds a valid key) and the key bias is the initial value of the QK^T accumulators: no running maximum, no bias add,
-//     no O rescale — 138 VALU instructions per tile instead of ~205, and with LDS-DMA staging 128 VGPRs, i.e. 4 waves
-//     per SIMD.  softmax is shift-invariant and fp32 keeps its relative precision at any exponent, so
+//     no O rescale, and the reference itself is added by the matrix core: one more link in the QK^T chain whose K-side
+//     fragment is the constant 1 and whose Q-side fragment holds the (16-bit rounded) reference, so a score leaves the
+//     MFMA as the exponent and the VALU does the bare v_exp_f32, the row-sum add and the 16-bit pack;
+//     with LDS-DMA staging 128 VGPRs, i.e. 4 waves per SIMD.  softmax is shift-invariant and fp32 keeps its relative precision at any exponent, so
 //     the result differs from the online form in rounding only, as long as nothing overflows.  Tiles without a valid
 //     key are skipped.  Returns true when the schedule did not hold: a row sum left 2^64 (6e4 with fp16 operands; a
 //     later score far above the reference — inf and NaN fail the test too), or the sequence has no valid key at all (a
@@ -100,14 +139,16 @@ template <int DT, bool DENSE, bool DIAG, bool FIXED>
 __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
   char* const k_img = lds;                       // [2][8 KiB]
   char* const v_img = lds + 2 * TILE_BYTES;      // [2][8 KiB]
-  float* const b_img = (float*)(lds + 4 * TILE_BYTES);  // [2][64] raw additive key bias
-  int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);   // [2] tile has a masked / out-of-range key
+  float* const b_all = (float*)(lds + 4 * TILE_BYTES);                        // [16][64] additive key bias of the chunk
+  int* const f_all = (int*)(lds + 4 * TILE_BYTES + BIAS_TILES * KT * 4);      // [16] tile flags
   const int Tq = a.Tq, Tk = a.Tk, kv_stride = a.kv_stride;
   const float* const key_bias = a.key_bias;
 
   const int b = grp / a.heads, head = grp - b * a.heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int qrow = qblk * 128 + wave * 32 + (lane & 31);
+  unsigned long long t_begin = 0;
+  if constexpr (DIAG) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin) :: "memory");
 
   // ---- Q fragments (B operand of S^T = K Q^T): Q[query = lane&31][d = 16 i + 8 h + j]
   bf16x8 qf[4];
@@ -128,7 +169,6 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
   const uint32_t ck0 = (uint32_t)((lane & 7) ^ (lane >> 4)) << 4;           // swz128: chunk ^ ((row >> 1) & 7); piece 1: ^ 4
   const uint32_t cv = (uint32_t)((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4;   // vswz: chunk ^ (((row >> 1) & 1) << 2)
   const uint32_t dst0 = __builtin_amdgcn_readfirstlane(lds_addr(k_img) + wave * 2048);
-  float br = 0.f;
 #define RR_LOAD_TILE(t, buf)                                                                    \
   {                                                                                             \
     const uint32_t ro0 = (uint32_t)min((t) * KT + r0, Tk - 1) * stride2;                        \
@@ -138,28 +178,19 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     glds16_so(kbase, ro1 + (ck0 ^ 64u), kd + 1024);                                             \
     glds16_so(vbase, ro0 + cv, kd + 2 * TILE_BYTES);                                            \
     glds16_so(vbase, ro1 + cv, kd + 2 * TILE_BYTES + 1024);                                     \
-    if (tid < KT) {                                                                             \
-      const int key = (t) * KT + tid;                                                           \
-      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;            \
-    }                                                                                           \
   }
-#define RR_WRITE_TILE(buf)                                                                      \
-  {                                                                                             \
-    if (tid < KT) {                                                                             \
-      b_img[(buf) * KT + tid] = br;                                                             \
-      const unsigned long long any = __ballot(br != 0.f);      /* wave 0 only: tid < 64 */     \
-      const unsigned long long valid = __ballot(br > -1e29f);                                   \
-      if (tid == 0) f_img[buf] = (any != 0ull ? 1 : 0) | (valid == 0ull ? 2 : 0);               \
-    }                                                                                           \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's four pieces have landed */ \
-  }
+#define RR_WRITE_TILE(buf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's four pieces have landed */
 
   f32x16 o0, o1;   // O^T[d = 32*dblk + (r&3) + 8(r>>2) + 4h][query = lane&31]
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;   // online: running max (raw score domain); this lane's partial row sum
-  float c_ref = 0.f;                      // fixed reference: -LOG2E * the row's reference maximum, 0 until there is one
-  bool need_ref = true;                   // (all rows of a workgroup see the same keys, so this flips for all lanes at once)
+  bool need_ref = true;                   // fixed reference: minus the row maximum of the first tile with a valid key
+                                          // (all rows of a workgroup see the same keys, so this flips for all lanes at once)
+  // the reference as one more k-step of S^T = K Q^T: K side = 1 at k = 0, Q side = reference at k = 0 (lanes with h = 0)
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+  // (both fragments are rebuilt from one register each per tile: at 128 VGPRs two resident quads would spill)
+  uint32_t kone0 = h == 0 ? (DT == 0 ? 0x3F80u : 0x3C00u) : 0u, qc0 = 0u;
 
   // diagnostic build: s_memtime marks per KV tile (read after the tile's barrier), summed per wave
   unsigned long long dg[5] = {0, 0, 0, 0, 0}, tmk[6];
@@ -167,19 +198,28 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
   const int nt = (Tk + KT - 1) / KT;
   const bool prio = (a.tuning & 1) != 0;
   RR_LOAD_TILE(0, 0)
+  load_bias_chunk(b_all, f_all, key_bias, b, Tk, 0);
   RR_WRITE_TILE(0)
+  // A wait the compiler can see: the LDS-DMA is counted by hand (asm), so without it hipcc's scoreboard still holds the Q
+  // loads as "in flight" on every trip of the loop and puts s_waitcnt vmcnt(6..3) in front of the QK^T MFMAs — which, with
+  // the next tile's four DMA pieces just issued, stalls the chain until two of them have LANDED.
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt unconstrained
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
+    if (__builtin_expect(t != 0 && (t & (BIAS_TILES - 1)) == 0, 0)) {      // sequences beyond 1024 keys: next bias chunk
+      load_bias_chunk(b_all, f_all, key_bias, b, Tk, t / BIAS_TILES);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
     RR_MARK(0)
     if (t + 1 < nt) RR_LOAD_TILE(t + 1, buf ^ 1)
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
-    const float* bt_ = b_img + buf * KT;
+    const float* bt_ = b_all + (t & (BIAS_TILES - 1)) * KT;
     // wave-uniform: some key of this tile carries a bias.  DENSE: an additive bias per (query, key) on top of the
     // per-key one (PreFLMR attention fusion, attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld],
     // dense_ld a multiple of 64, zero padded; it only exists in the online form.
-    const int tile_flags = __builtin_amdgcn_readfirstlane(f_img[buf]);   // bit 0: some key has a bias; bit 1: no valid key
+    const int tile_flags = __builtin_amdgcn_readfirstlane(f_all[t & (BIAS_TILES - 1)]);   // bit 0: some key has a bias; bit 1: no valid key
     const bool masked = DENSE || (tile_flags & 1);
     // Fixed-reference form only: a tile without a single valid key (tail padding) adds exactly 0 to every row sum and to
     // O, so its QK^T, softmax and P.V are skipped (the staging of the next tile and the barrier
@@ -191,6 +231,13 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     f32x16 s0, s1;
     auto qk = [&]() __attribute__((always_inline)) {
       if (prio) __builtin_amdgcn_s_setprio(2);   // MFMA sections outrank the softmax VALU of the co-resident waves
+      if constexpr (FIXED) {     // + reference: register operands only, so it runs under the first K fragments' LDS latency
+        asm volatile("" : "+v"(kone0), "+v"(qc0));
+        const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4_{kone0, 0u, 0u, 0u});
+        const bf16x8 qc = __builtin_bit_cast(bf16x8, u32x4_{qc0, 0u, 0u, 0u});
+        s0 = mfma32<DT>(kone, qc, s0);
+        s1 = mfma32<DT>(kone, qc, s1);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bf16x8 k0 = *(const bf16x8*)(kt_ + swz128(lane & 31, 2 * i + h));
@@ -227,26 +274,34 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     if constexpr (FIXED) {
       if (__builtin_expect(need_ref, 0)) {        // first tile(s) only: take the reference from the first valid keys
         const float mx = row_max();
-        if (mx > -1e29f) { c_ref = -mx * LOG2E; need_ref = false; }
+        if (mx > -1e29f) {
+          float c_ref;
+          const uint32_t c16 = ref16<DT>(-mx, c_ref);     // any reference near the maximum does: the rounded one is used throughout
+          qc0 = h == 0 ? c16 : 0u;
+          need_ref = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s0[r] += c_ref; s1[r] += c_ref; }   // this tile's chain ran without it
+        }
       }
-      // one fused multiply-add and the bare v_exp_f32 per score: a masked key is (-1e30 + q.k) -> 0 (also while there is
-      // no reference yet: c_ref = 0), a key beyond Tk is -inf -> 0
+      // the bare v_exp_f32 per score: a masked key is (-1e30 + q.k + ref) -> 0, a key beyond Tk is -inf -> 0
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c_ref));
-        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c_ref));
+        s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r]);
       }
     } else {
-      // ---- online softmax.  Running max m_run is kept in the RAW score domain; exponentials are exp2 of
-      // LOG2E-scaled differences on the bare v_exp_f32 (arguments are <= 0, a flushed denormal is an exact 0 here).
+      // ---- online softmax.  Scores and the running max m_run are in the log2 domain (Q is pre-scaled); exponentials
+      // are the bare v_exp_f32 of differences (arguments are <= 0, a flushed denormal is an exact 0 here).
       if constexpr (DENSE) {
         const float* dp = a.dense_bias + ((size_t)b * Tq + min(qrow, Tq - 1)) * a.dense_ld + t * KT + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 d0 = *(const float4*)(dp + 8 * g);
           const float4 d1 = *(const float4*)(dp + 32 + 8 * g);
-          s0[4 * g + 0] += d0.x; s0[4 * g + 1] += d0.y; s0[4 * g + 2] += d0.z; s0[4 * g + 3] += d0.w;
-          s1[4 * g + 0] += d1.x; s1[4 * g + 1] += d1.y; s1[4 * g + 2] += d1.z; s1[4 * g + 3] += d1.w;
+          s0[4 * g + 0] = fmaf(d0.x, LOG2E, s0[4 * g + 0]); s0[4 * g + 1] = fmaf(d0.y, LOG2E, s0[4 * g + 1]);
+          s0[4 * g + 2] = fmaf(d0.z, LOG2E, s0[4 * g + 2]); s0[4 * g + 3] = fmaf(d0.w, LOG2E, s0[4 * g + 3]);
+          s1[4 * g + 0] = fmaf(d1.x, LOG2E, s1[4 * g + 0]); s1[4 * g + 1] = fmaf(d1.y, LOG2E, s1[4 * g + 1]);
+          s1[4 * g + 2] = fmaf(d1.z, LOG2E, s1[4 * g + 2]); s1[4 * g + 3] = fmaf(d1.w, LOG2E, s1[4 * g + 3]);
         }
       }
       if (masked) {
@@ -259,23 +314,14 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
         }
       }
       const float m_new = fmaxf(m_run, row_max());     // finite: every tile has >= 1 in-range key
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // first tile: exp2(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
       m_run = m_new;
-      if (masked) {
-        // (s + bias) - m is exactly 0 for a fully masked row (all entries -1e30): uniform attention, as the
-        // reference's finfo.min mask gives; a fused multiply-add form would not cancel exactly.
+      // (s + bias) - m is exactly 0 for a fully masked row (all entries -1e30): uniform attention, as the reference's
+      // finfo.min mask gives
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
-          s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
-        }
-      } else {
-        const float c = -m_new * LOG2E;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], LOG2E, c));
-          s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], LOG2E, c));
-        }
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
       }
       l_run *= alpha;
 #pragma unroll
@@ -333,6 +379,17 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     if (a.stamps && lane == 0)
       for (int k_ = 0; k_ < 5; ++k_) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = dg[k_];
     if (a.stamps && tid == 0) a.stamps[((size_t)blockIdx.x * 4) * 8 + 7] = (unsigned long long)nt;
+    // wave lifetime (entry .. end of the tile loop) and where it ran: slot 5 / 6 = s_memtime, slot 7 of waves 1..3 =
+    // XCC_ID << 32 | HW_ID (tools/attn_timeline.py derives the clock and the waves resident per SIMD from these)
+    unsigned long long t_end;
+    uint32_t hw, xcc;
+    asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(t_end), "=s"(hw), "=s"(xcc) :: "memory");
+    if (a.stamps && lane == 0) {
+      a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 5] = t_begin;
+      a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 6] = t_end;
+      if (wave) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
   }
 #undef RR_MARK
 #undef RR_LOAD_TILE
@@ -368,8 +425,8 @@ template <int DT>
 __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
   char* const k_img = lds;
   char* const v_img = lds + 2 * TILE_BYTES;
-  float* const b_img = (float*)(lds + 4 * TILE_BYTES);
-  int* const f_img = (int*)(lds + 4 * TILE_BYTES + 2 * KT * 4);
+  float* const b_all = (float*)(lds + 4 * TILE_BYTES);
+  int* const f_all = (int*)(lds + 4 * TILE_BYTES + BIAS_TILES * KT * 4);
   const int Tq = a.Tq, Tk = a.Tk, kv_stride = a.kv_stride;
   const float* const key_bias = a.key_bias;
   const int b = grp / a.heads, head = grp - b * a.heads;
@@ -392,7 +449,6 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
   const uint32_t ck0 = (uint32_t)((lane & 7) ^ (lane >> 4)) << 4;
   const uint32_t cv = (uint32_t)((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 4;
   const uint32_t dst0 = __builtin_amdgcn_readfirstlane(lds_addr(k_img) + wave * 2048);
-  float br = 0.f;
   auto load_tile = [&](const int t, const int buf) __attribute__((always_inline)) {
     const uint32_t ro0 = (uint32_t)min(t * KT + r0, Tk - 1) * stride2;
     const uint32_t ro1 = (uint32_t)min(t * KT + r0 + 8, Tk - 1) * stride2;
@@ -401,40 +457,37 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     glds16_so(kbase, ro1 + (ck0 ^ 64u), kd + 1024);
     glds16_so(vbase, ro0 + cv, kd + 2 * TILE_BYTES);
     glds16_so(vbase, ro1 + cv, kd + 2 * TILE_BYTES + 1024);
-    if (tid < KT) {
-      const int key = t * KT + tid;
-      br = key < Tk ? (key_bias ? key_bias[(size_t)b * Tk + key] : 0.f) : -INFINITY;
-    }
   };
-  auto write_tile = [&](const int buf) __attribute__((always_inline)) {
-    if (tid < KT) {
-      b_img[buf * KT + tid] = br;
-      const unsigned long long any = __ballot(br != 0.f);
-      const unsigned long long valid = __ballot(br > -1e29f);
-      if (tid == 0) f_img[buf] = (any != 0ull ? 1 : 0) | (valid == 0ull ? 2 : 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
+  auto write_tile = [&](const int) __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   f32x16 o[2][2];
 #pragma unroll
   for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[sb][0][r] = 0.f; o[sb][1][r] = 0.f; }
-  float l_run[2] = {0.f, 0.f}, c_ref[2] = {0.f, 0.f};
+  float l_run[2] = {0.f, 0.f};
   bool need_ref = true;
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+  const bf16x8 kone = __builtin_bit_cast(bf16x8, u32x4_{h == 0 ? (DT == 0 ? 0x3F80u : 0x3C00u) : 0u, 0u, 0u, 0u});
+  bf16x8 qc[2] = {__builtin_bit_cast(bf16x8, u32x4_{0u, 0u, 0u, 0u}), __builtin_bit_cast(bf16x8, u32x4_{0u, 0u, 0u, 0u})};
   const int nt = (Tk + KT - 1) / KT;
   const bool prio = (a.tuning & 1) != 0;
   load_tile(0, 0);
+  load_bias_chunk(b_all, f_all, key_bias, b, Tk, 0);
   write_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // compiler-visible vmcnt(0): see attn_block
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
+    if (__builtin_expect(t != 0 && (t & (BIAS_TILES - 1)) == 0, 0)) {
+      load_bias_chunk(b_all, f_all, key_bias, b, Tk, t / BIAS_TILES);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
     if (t + 1 < nt) load_tile(t + 1, buf ^ 1);
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
-    const float* bt_ = b_img + buf * KT;
-    const int tile_flags = __builtin_amdgcn_readfirstlane(f_img[buf]);   // bit 0: some key has a bias; bit 1: no valid key
+    const float* bt_ = b_all + (t & (BIAS_TILES - 1)) * KT;
+    const int tile_flags = __builtin_amdgcn_readfirstlane(f_all[t & (BIAS_TILES - 1)]);   // bit 0: some key has a bias; bit 1: no valid key
     const bool masked = (tile_flags & 1) != 0;
     if (!(tile_flags & 2)) {     // a tile without a valid key adds exactly 0: skipped (see attn_block)
 
@@ -451,6 +504,11 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     f32x16 s[2][2];     // [sub-block][key half]
     auto qk = [&]() __attribute__((always_inline)) {
       if (prio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {     // + the row's fixed reference (see attn_block)
+        s[sb][0] = mfma32<DT>(kone, qc[sb], s[sb][0]);
+        s[sb][1] = mfma32<DT>(kone, qc[sb], s[sb][1]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -498,7 +556,14 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[sb][0][r], s[sb][1][r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (mx > -1e29f) { c_ref[sb] = -mx * LOG2E; got = true; }
+        if (mx > -1e29f) {
+          float c_ref;
+          const uint32_t c16 = ref16<DT>(-mx, c_ref);
+          qc[sb] = __builtin_bit_cast(bf16x8, u32x4_{h == 0 ? c16 : 0u, 0u, 0u, 0u});
+          got = true;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[sb][0][r] += c_ref; s[sb][1][r] += c_ref; }
+        }
       }
       if (got) need_ref = false;       // validity is a property of the keys: both sub-blocks and all lanes agree
     }
@@ -507,8 +572,8 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[sb][0][r] = __builtin_amdgcn_exp2f(fmaf(s[sb][0][r], LOG2E, c_ref[sb]));
-        s[sb][1][r] = __builtin_amdgcn_exp2f(fmaf(s[sb][1][r], LOG2E, c_ref[sb]));
+        s[sb][0][r] = __builtin_amdgcn_exp2f(s[sb][0][r]);
+        s[sb][1][r] = __builtin_amdgcn_exp2f(s[sb][1][r]);
       }
       f32x2v acc2 = {0.f, 0.f};
 #pragma unroll
@@ -622,11 +687,12 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
 static unsigned long long* g_attn_stamps = nullptr;
 // kernel argument `tuning`: bit 0 = rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention).
 // rr_set_tuning("attn_fixed_ref"): fixed-reference schedule (two launches) for grids of at least ATTN_FIXED_MIN_BLOCKS.
-constexpr int ATTN_FIXED_DEFAULT = 1;   // 0 online only, 1 fixed reference (32 rows per wave), 2 fixed reference (64 rows per wave)
+constexpr int ATTN_FIXED_DEFAULT = 3;   // 0 online only, 1 fixed reference (32 rows per wave), 2 fixed reference (64 rows per wave),
+                                        // 3 = 2 where 256-row workgroups pad no more query rows than 128-row ones do, else 1
 static int g_attn_prio_host = 1, g_attn_fixed_host = ATTN_FIXED_DEFAULT;
 constexpr long ATTN_FIXED_MIN_BLOCKS = 1024;   // below this the launch, not the softmax, is what costs
 extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; }
-extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 2) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
+extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 3) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
   return 0;
@@ -689,7 +755,11 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
   if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {
-    if (g_attn_fixed_host == 2 && !diag) {     // 64 query rows per wave: 256-row workgroups, flags per 256-row workgroup
+    // 64 query rows per wave: 256-row workgroups, flags per 256-row workgroup.  Half the K/V fragment reads and DMA pieces
+    // per query row (the launch is clock-limited by power: fewer LDS bytes per MFMA is what it answers to), at 2 waves per
+    // SIMD; padding to 256 rows must not cost more than that saves.
+    const bool rows64 = g_attn_fixed_host == 2 || (g_attn_fixed_host == 3 && ((Tq + 255) / 256) * 2 == (Tq + 127) / 128);
+    if (rows64 && !diag) {
       const long nblk64 = ((groups + 7) / 8) * 8 * ((Tq + 255) / 256);
       a.nblk = (int)nblk64;
       hipError_t e = attn_flags(nblk64, st, &a.flags);

@@ -453,7 +453,7 @@ int up_fp8(rr_model* m, const std::vector<float>& W, size_t cols, uint8_t** w_ou
 
 // prev_ln: state_dict prefix of the LayerNorm whose output feeds this layer's QKV ("" = none: first layer of a stack)
 int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross, LayerW* L, const std::string& prev_ln = "") {
-  const float qs = 1.0f / sqrtf((float)(Hd / heads));   // 1/sqrt(dh): 0.125 for dh = 64 (exact in bf16)
+  const float qs = 1.4426950408889634f / sqrtf((float)(Hd / heads));   // log2(e)/sqrt(dh): the attention kernels take base-2 exponentials of Q K^T as it is
   const std::string a = p + ".attention";
   RR_TRY(up_bf16(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs), &L->wqkv));
   RR_TRY(up_f32(m, cat({&HT(m, a + ".self.query.bias"), &HT(m, a + ".self.key.bias"), &HT(m, a + ".self.value.bias")}, qs), &L->bqkv));
@@ -496,7 +496,7 @@ int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross,
 
 // CLIPEncoderLayer: q/k/v fused with CLIP's q scaling (dh^-0.5 applied to q_proj's output, bias included) folded in
 int pack_vit_layer(rr_model* m, const std::string& l, int heads, int Vh, LayerW* L) {
-  const float qs = 1.0f / sqrtf((float)(Vh / heads));
+  const float qs = 1.4426950408889634f / sqrtf((float)(Vh / heads));   // log2(e)/sqrt(dh), as pack_layer
   const std::string a = l + ".self_attn";
   RR_TRY(up_bf16(m, cat({&HT(m, a + ".q_proj.weight"), &HT(m, a + ".k_proj.weight"), &HT(m, a + ".v_proj.weight")}, qs), &L->wqkv));
   RR_TRY(up_f32(m, cat({&HT(m, a + ".q_proj.bias"), &HT(m, a + ".k_proj.bias"), &HT(m, a + ".v_proj.bias")}, qs), &L->bqkv));

@@ -89,7 +89,7 @@ def _attn_ref(q, k, v, bias, heads, qdiv=1):
     qh = qq.view(B, Tq, heads, 64).transpose(1, 2)
     kh = k.float().view(B, Tk, heads, 64).transpose(1, 2)
     vh = v.float().view(B, Tk, heads, 64).transpose(1, 2)
-    s = qh @ kh.transpose(-1, -2)                     # q is pre-scaled
+    s = (qh @ kh.transpose(-1, -2)) * math.log(2.0)   # q arrives pre-scaled by log2(e)/sqrt(dh): the kernel's exponentials are base 2
     if bias is not None:
         s = s + bias[:, None, None, :]
     return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, heads * 64)
@@ -200,8 +200,8 @@ def _run_attn(lib, q, k, v, bias, heads):
 def test_attention_fixed_reference_schedule(lib, dt, mode):
     """The default schedule (two launches, grids >= 1024 workgroups) takes the row maximum of the first tile with a valid
     key as a fixed softmax reference; workgroups where a row sum leaves 2^64, or that see no valid key at all, are
-    recomputed in the online form by the second launch.  Cases: (a) a later tile 20 nats above the reference stays on
-    the fixed path; (b) 230 nats above it overflows and is recomputed; (c) left padding (tile 0 fully masked) takes its
+    recomputed in the online form by the second launch.  Cases: (a) a later tile 2^20 above the reference stays on
+    the fixed path; (b) 2^230 above it overflows and is recomputed; (c) left padding (tile 0 fully masked) takes its
     reference from tile 1; (d) a pair with no valid key is recomputed and comes out uniform.  All against the fp32
     reference and against the online-only schedule of the same kernel.  dt = 1: fp16 operands, where P itself must stay
     below 65504, so (a) is recomputed as well."""

@@ -59,3 +59,34 @@ for name, bias in (("no mask", 0), ("masked path", kb.data_ptr()), ("no valid ke
     for k, nm in enumerate(names):
         print(f"  {nm:26s} {seg[:, :, k].mean():7.1f} cycles per KV tile   by wave " + " ".join(f"{seg[:, w, k].mean():6.0f}" for w in range(4)))
     print(f"  sum {seg.sum(-1).mean():.0f} cycles per KV tile per wave")
+    # wave lifetimes and placement: clock = cycles between the first entry and the last exit / the launch's wall time;
+    # residency = sum of lifetimes / (span x SIMDs that hosted a wave)
+    raw = buf.view(nblk, 4, 8)
+    live = raw[:, 1:, 5] > 0
+    t0, t1, where = raw[:, 1:, 5][live], raw[:, 1:, 6][live], raw[:, 1:, 7][live]
+    if t0.numel():
+        lib.rr_set_attn_stamps(buf.data_ptr())
+        run(bias); torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            run(bias)
+        ev1.record(); torch.cuda.synchronize()
+        lib.rr_set_attn_stamps(0)
+        ms_d = ev0.elapsed_time(ev1) / 5
+        xcc = (where >> 32) & 0xf
+        hw = where & 0xffffffff
+        simd_key = (xcc << 16) | (hw & 0xff30)               # HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+        keys = torch.unique(simd_key)
+        life = (t1 - t0).double()
+        spans, resident = [], []
+        for kx in keys[:: max(1, keys.numel() // 64)].tolist():      # a sample of SIMDs: one time base each
+            m = simd_key == kx
+            sp = float((t1[m].max() - t0[m].min()).item())
+            spans.append(sp)
+            resident.append(life[m].sum().item() * 4 / 3 / sp)
+        spans, resident = torch.tensor(spans), torch.tensor(resident)
+        print(f"  diagnostic build, 5 launches back to back: {ms_d:.3f} ms each; per-SIMD span median {spans.median():.0f} cycles "
+              f"(min {spans.min():.0f}, max {spans.max():.0f}) -> {spans.median().item() / ms_d / 1e6:.2f} GHz if the span is the launch")
+        print(f"  wave lifetime mean {life.mean():.0f} cycles (tile loop {seg.sum(-1).mean() * float(nt.mean()):.0f}); {keys.numel()} distinct (XCC, SE, SH, CU, SIMD) ids; "
+              f"resident waves per SIMD: median {resident.median():.2f} (min {resident.min():.2f}, max {resident.max():.2f})")
