@@ -13,8 +13,9 @@ import glob
 import json
 import sys
 
-CLASSES = [("gemm", "gemm_kernel"), ("attention", "attn_fwd"), ("attention", "attn_fixed"), ("attention_redo", "attn_redo"),
-           ("layernorm", "layernorm_kernel"),
+CLASSES = [("gemm_fp8", "gemm_kernel_hp8"), ("gemm_fp8", "gemm_kernel_f8"), ("gemm", "gemm_kernel"), ("attention", "attn_fwd"),
+           ("attention", "attn_fixed"), ("attention_redo", "attn_redo"),
+           ("layernorm", "layernorm_kernel"), ("layernorm", "layernorm_q8"), ("ln_finalize", "ln_finalize"),
            ("embed", "embed_ln"), ("other", "")]
 
 

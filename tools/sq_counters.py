@@ -20,7 +20,7 @@ import json
 import re
 import sys
 
-PAT = re.compile(r"((gemm_kernel_hp|attn_fixed_kernel|attn_fwd_kernel|layernorm_kernel)(<[^>]*>)?)")
+PAT = re.compile(r"((gemm_kernel_hp8|gemm_kernel_hp|attn_fixed64_kernel|attn_fixed_kernel|attn_fwd_kernel|layernorm_kernel)(<[^>]*>)?)")
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for d in sys.argv[1:3]:
