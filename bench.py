@@ -71,6 +71,9 @@ def parse_args(argv=None):
                          "residual stream, LayerNorm, softmax stay fp32).  bf16 (what the reference's autocast uses) drifts "
                          "2e-3..1e-2 from fp32 in ANY implementation, the reference's own included (tests/golden/autocast.npz)")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the extra timing of the other operand type (N=1 only)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks time-share cuda:0 and exchange over gloo: exercises the spawn / shard / gather / head "
+                         "path with the real engine on a one-GPU box; the line is marked, it is NOT a scaling measurement")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="process-wide A/B switch of the library (rr_set_tuning), e.g. --tuning ln_fold=0; diagnostic")
     a = ap.parse_args(argv)
@@ -214,13 +217,18 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ    # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")          # RCCL refuses two ranks on one device; the gather is staged through the host
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import rmr_amd
     from rmr_amd.sharding import sharded_forward
@@ -285,7 +293,7 @@ def main():
     prof = eng.get_profile(reset=True) if not args.no_profile else None
     step_ms = [a.elapsed_time(b) for a, b in ev]
     if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out["logits"]).all()
@@ -308,8 +316,10 @@ def main():
             "config": {"workload": (names[wl] if not args.text_only else "c3-text: text-only cross-encoder rerank (Lc=1)")
                        + f", K={K}, seq_len={S}, vision_tokens={P}",
                        "queries_per_step": Bq, "pairs_per_step": N, "token_regime": args.regime,
-                       "parallelism": f"pairs sharded over {world} GPU(s) ({nranks_seen} rank(s) in the process group), "
-                                      "1 RCCL all-gather of logits/step",
+                       "parallelism": (f"REHEARSAL: {world} ranks time-sharing ONE GPU, logits exchanged over gloo through the host; "
+                                       "not a scaling measurement") if args.rehearse_one_gpu else
+                                      (f"pairs sharded over {world} GPU(s) ({nranks_seen} rank(s) in the process group), "
+                                       "1 RCCL all-gather of logits/step"),
                        "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"},
             "step_ms_device": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
                                "n": len(step_ms), "note": "HIP events around each timed step on the work stream, rank 0"},

@@ -33,6 +33,7 @@ class _GatherPlan:
     def __init__(self, device, dtype, world: int, n_pairs: int, heads: int):
         self.world, self.n, self.heads = world, n_pairs, heads
         self.per = -(-n_pairs // world)                                  # ceil(N / W): the padded slice length
+        self.host = None
         self.send = torch.zeros(heads * self.per, dtype=dtype, device=device)
         self.recv = torch.empty(world * heads * self.per, dtype=dtype, device=device)
         self.ragged = n_pairs % world != 0
@@ -68,7 +69,15 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
     p.send[:n_loc].copy_(local.reshape(-1))
     if local2 is not None:
         p.send[p.per: p.per + n_loc].copy_(local2.reshape(-1))
-    dist.all_gather_into_tensor(p.recv, p.send, group=group)
+    if p.send.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on one GPU (bench.py --rehearse-one-gpu): gloo has no device all-gather, stage through the host
+        if p.host is None:
+            p.host = (torch.empty_like(p.send, device="cpu").pin_memory(), torch.empty_like(p.recv, device="cpu").pin_memory())
+        p.host[0].copy_(p.send)
+        dist.all_gather_into_tensor(p.host[1], p.host[0], group=group)
+        p.recv.copy_(p.host[1])
+    else:
+        dist.all_gather_into_tensor(p.recv, p.send, group=group)
     if not p.ragged:
         if heads == 1:
             return p.recv, None                                       # rank-major == pair order: the block IS the vector
