@@ -334,6 +334,15 @@ int rr_op_amax(const void* x, int x_is_f32, size_t n, float* out_dev, void* hip_
  *     epi(LayerNorm(x) W^T + b) for the raw rows x whose 16-bit copy is A_raw. */
 int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N, int Kd,
                             float eps, float* out_f32, uint16_t* x16_out, float* stats_out, float* part_scratch, void* hip_stream);
+/* The same residual epilogue on the SPLIT residual stream: a pre-LayerNorm row x travels as hi = its 16-bit
+ * operand rounding (the consumer GEMM's A rows) + lo = fp16(x - hi) instead of a separate fp32 copy.  Residual rows come in as
+ * (hi_in, lo_in) [M,N] — normalised on the fly with (ln_stats [M,2], ln_gamma, ln_beta) when ln_stats != NULL — and the output
+ * rows x = A W^T + bias + residual leave as (x16_out, lo_out) plus their statistics; hi_in == x16_out and lo_in == lo_out
+ * (in place) is allowed.  Only for shapes the persistent ring kernel runs (>= 512 tiles of 256 x 256, N % 8 == 0), otherwise
+ * RR_ERR_UNSUPPORTED. */
+int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in, const uint16_t* lo_in,
+                           const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
+                           uint16_t* x16_out, uint16_t* lo_out, float* stats_out, float* part_scratch, void* hip_stream);
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream);
 /* LayerNorm whose output is an fp8 GEMM operand: out8[row] = e4m3(LN(x[row]) / row_scale[row]), row_scale = row amax / 448,

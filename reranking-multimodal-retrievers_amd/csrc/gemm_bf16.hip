@@ -116,6 +116,11 @@ struct LnResid {
   const float2* in_stats;
   const float* csum;
   int flags;             // bit 0: touch the next pass's residual lines a pass ahead (rr_set_tuning "resid_touch")
+  // split residual stream (GemmFold, rr_common.h): residual rows as hi + lo, output rows as x16 + lo_out
+  const bf16_t* r_hi;
+  const bf16_t* r_lo;
+  int ld16;
+  bf16_t* lo_out;
 };
 // Sum over aligned groups of 32 consecutive lanes, broadcast to every lane of the group, on the DPP data path (VALU
 // operand modifiers: no LDS-crossbar ds_bpermute; 80 of those per pass cost the residual epilogue +24 %): a 16-lane row
@@ -138,6 +143,18 @@ __device__ __forceinline__ float group32_sum(float v) {
   const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 31));
   const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
   return (threadIdx.x & 32) ? hi : lo;
+}
+// Sum over aligned groups of 16 consecutive lanes (a DPP row), every lane of the group gets the total: four rotations.
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_rot<0x128>(v);      // row_ror:8
+  v += dpp_rot<0x124>(v);      // row_ror:4
+  v += dpp_rot<0x122>(v);      // row_ror:2
+  v += dpp_rot<0x121>(v);      // row_ror:1
+  return v;
 }
 // Producer side of the folded LayerNorm for one 16-byte chunk (4 consecutive columns gcol..gcol+3 of row gm) of the
 // staged fp32 epilogue; lanes of an aligned group of 32 hold the 32 chunks of one 128-column group of ONE row.  Every
@@ -807,7 +824,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 // main loop's last barrier); the epilogue stages through the other half of the LDS ([80 KiB, 160 KiB), two 128-row passes
 // for 16-bit output, four 64-row passes for fp32), so the 5-6k-cycle cold prologue of every tile but the first hides
 // behind the previous tile's epilogue.  Same main loop, same arithmetic, same results as gemm_kernel_h.
-template <int EPI, int DT>
+// SPLIT (EPI_BIAS_RESID_F32 only): bit 0 = the residual rows come as the (hi, lo) pair, bit 1 = the output rows leave as one.
+template <int EPI, int DT, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__ A, int lda,
                                                      const bf16_t* __restrict__ W, int ldw,
                                                      const float* __restrict__ bias,
@@ -1126,11 +1144,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         }
       }
     }
-    const int my_col = cn0 + (tid % CPR) * (16 / ES);
-    float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int my_col = (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0) ? cn0 + (tid & 31) * 8 : cn0 + (tid % CPR) * (16 / ES);
+    float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f), lg1 = lg, lb1 = lb;   // lg1 / lb1: split path, columns +4..+7
     if (EPI == EPI_BIAS_RESID_F32 && ln.stats && my_col < N) {
       lg = *(const float4*)(ln.gamma + my_col);
       lb = *(const float4*)(ln.beta + my_col);
+      if constexpr (SPLIT != 0) { lg1 = *(const float4*)(ln.gamma + my_col + 4); lb1 = *(const float4*)(ln.beta + my_col + 4); }
     }
     // The residual rows of a pass are first touched by a register-free LDS-DMA, one 128-byte line per thread (64 rows x
     // 1 KiB = 512 lines), a pass ahead of the loads that consume them: the loads behind the barrier then find their lines
@@ -1139,9 +1158,16 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     auto touch_resid = [&](int pass_) {
       if (EPI != EPI_BIAS_RESID_F32 || !(ln.flags & 1)) return;
       if (cm0 + 256 > M || cn0 + 256 > N) return;                   // ragged last tiles: not worth a clamp per lane
-      const float* sb = resid + (size_t)(cm0 + (pass_ >> 1) * 128 + (pass_ & 1) * 64) * ldr + cn0;   // scalar
-      const uint32_t vo = (uint32_t)(((tid >> 3) * ldr + (tid & 7) * 32) * 4);                        // line `tid` of the 64 x 256 block
-      glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+      const size_t row0 = (size_t)(cm0 + (pass_ >> 1) * 128 + (pass_ & 1) * 64);
+      if constexpr ((SPLIT & 1) != 0) {   // split residual: 64 rows x 512 B of hi (waves 0-3) and of lo (waves 4-7), one 128-byte line per thread
+        const bf16_t* sb = (wave < 4 ? ln.r_hi : ln.r_lo) + row0 * ln.ld16 + cn0;                     // scalar
+        const uint32_t vo = (uint32_t)((((tid & 255) >> 2) * ln.ld16 + (tid & 3) * 64) * 2);
+        glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+      } else {
+        const float* sb = resid + row0 * ldr + cn0;                                                     // scalar
+        const uint32_t vo = (uint32_t)(((tid >> 3) * ldr + (tid & 7) * 32) * 4);                        // line `tid` of the 64 x 256 block
+        glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+      }
     };
     static_assert(!F32_OUT || 5 * HALF + ROWS * PITCH + 8 * 256 <= 160 * 1024, "touch area must fit behind the staging image");
     touch_resid(0);
@@ -1160,6 +1186,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             // 8 bytes per lane: 2-way, 8.7 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); rows with bit 3 set
             // keep the two 8-byte halves of every 16-byte chunk swapped, the reader swaps them back
             char* dst = stg + r * PITCH + (F32_OUT ? cn * ES : ((cn * ES) ^ (lane & 8)));
+            if constexpr (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0)       // even 16-byte chunks | odd 16-byte chunks (see the stream-out)
+              dst = stg + r * PITCH + (((cn >> 3) << 4) | (((cn >> 2) & 1) << 9));
             if constexpr (F32_OUT) *(f32x4*)dst = acc[q][nt][mt];
             else *(uint2*)dst = make_uint2(pack2<DT>(acc[q][nt][mt][0], acc[q][nt][mt][1]),
                                            pack2<DT>(acc[q][nt][mt][2], acc[q][nt][mt][3]));
@@ -1172,6 +1200,94 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       if (pass + 1 < NPASS) touch_resid(pass + 1);
       lds_barrier();
       const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
+      if constexpr (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0) {
+        // ---- split residual stream (GemmFold in rr_common.h).  A thread owns 4 chunks of EIGHT columns per pass, so that the
+        // 16-bit rows move as 16 bytes per lane (8-byte accesses reach 0.54-0.70x of the 16-byte rate: the first version of
+        // this path, with the 4-column chunks of the fp32 form, moved 20 % fewer bytes and was 0.5 % slower).  A wave covers
+        // two rows per step (lanes 0-31 / 32-63), a 128-column group is one DPP row of 16 lanes.  The staging image keeps
+        // the even 16-byte chunks of a row in its first 512 bytes and the odd ones in the second, so that the two reads
+        // of a lane are each 16 consecutive bytes per lane across a 16-lane group (conflict-free).
+        constexpr int UN8 = 4;
+        static_assert(ROWS * 32 == 512 * UN8, "one batch of four 8-column chunks per thread and pass");
+        const int c8 = tid & 31, gcol = cn0 + c8 * 8;
+        const bool col_ok = gcol < N;                                     // N % 8 == 0: a chunk is inside or outside as a whole
+        uint4 rh[UN8], rl[UN8];
+        float4 ra[(SPLIT & 1) ? 1 : UN8], rb[(SPLIT & 1) ? 1 : UN8];
+        float2 rst[UN8];
+#pragma unroll
+        for (int u = 0; u < UN8; ++u) {
+          const int r = (tid >> 5) + u * 16, gm = row_base + r;
+          const bool ok = gm < M && col_ok;
+          if constexpr ((SPLIT & 1) != 0) {
+            rh[u] = ok ? *(const uint4*)(ln.r_hi + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
+            rl[u] = ok ? *(const uint4*)(ln.r_lo + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
+          } else {
+            ra[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          rst[u] = ln.stats ? ln.stats[min(gm, M - 1)] : make_float2(0.f, 1.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UN8; ++u) {
+          const int r = (tid >> 5) + u * 16, gm = row_base + r;
+          const bool ok = gm < M && col_ok;
+          float x[8];
+          if constexpr ((SPLIT & 1) != 0) {      // x = hi (operand type) + lo (fp16)
+            const uint32_t hw[4] = {rh[u].x, rh[u].y, rh[u].z, rh[u].w}, lw[4] = {rl[u].x, rl[u].y, rl[u].z, rl[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float2 h = unpack2<DT>(hw[j]), l = unpack2<1>(lw[j]);
+              x[2 * j] = h.x + l.x; x[2 * j + 1] = h.y + l.y;
+            }
+          } else {
+            x[0] = ra[u].x; x[1] = ra[u].y; x[2] = ra[u].z; x[3] = ra[u].w;
+            x[4] = rb[u].x; x[5] = rb[u].y; x[6] = rb[u].z; x[7] = rb[u].w;
+          }
+          if (ln.stats) {
+            const float ga[8] = {lg.x, lg.y, lg.z, lg.w, lg1.x, lg1.y, lg1.z, lg1.w};
+            const float ba[8] = {lb.x, lb.y, lb.z, lb.w, lb1.x, lb1.y, lb1.z, lb1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (x[j] - rst[u].x) * rst[u].y * ga[j] + ba[j];
+          }
+          const float4 v0 = *(const float4*)(stg + r * PITCH + c8 * 16);           // columns gcol .. gcol+3
+          const float4 v1 = *(const float4*)(stg + r * PITCH + 512 + c8 * 16);     // columns gcol+4 .. gcol+7
+          float f[8] = {v0.x + x[0], v0.y + x[1], v0.z + x[2], v0.w + x[3], v1.x + x[4], v1.y + x[5], v1.z + x[6], v1.w + x[7]};
+          if (!ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+          }
+          uint32_t hi[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
+          if (ok) {
+            *(uint4*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
+              uint32_t lo[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float2 hb = unpack2<DT>(hi[j]);
+                lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
+              }
+              *(uint4*)(ln.lo_out + (size_t)gm * ln.ld16 + gcol) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            } else {
+              float* cp = (float*)Cv + (size_t)gm * ldc + gcol;
+              *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
+              *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
+          }
+          // LayerNorm statistics of the 128-column group = the 16 lanes of this DPP row (every lane takes part)
+          const int grp = gcol >> 7;
+          const float rcnt = __builtin_amdgcn_rcpf((float)max(1, min(128, N - (grp << 7))));
+          const float mg = row16_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) * rcnt;
+          float q = 0.f;
+          if (ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
+          }
+          const float m2 = row16_sum(q);
+          if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
+        }
+      } else {
       // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
       // add/store (a wave keeps one row per step: its LayerNorm statistics are a scalar load)
       constexpr int UNR = 8;
@@ -1212,6 +1328,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
         // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)
         if (EPI == EPI_BIAS_RESID_F32) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
+      }
       }
       lds_barrier();                                       // staging image consumed (next pass / next tile may overwrite it)
     }
@@ -1285,6 +1402,27 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
                        tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);                                   \
     break;                                                                                                    \
   }
+  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
+  if (split && epilogue != EPI_BIAS_RESID_F32) return hipErrorInvalidValue;
+#define RR_GEMM_SPLIT_CASE(S)                                                                                 \
+  case S: {                                                                                                   \
+    auto kern = gemm_kernel_hp<EPI_BIAS_RESID_F32, DT, S>;                                                    \
+    static std::atomic<unsigned long long> attr_mask{0};                                                      \
+    {                                                                                                         \
+      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
+      if (e != hipSuccess) return e;                                                                          \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
+                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);       \
+    return hipGetLastError();                                                                                 \
+  }
+  switch (split) {
+    case 0: break;
+    RR_GEMM_SPLIT_CASE(1)
+    RR_GEMM_SPLIT_CASE(2)
+    RR_GEMM_SPLIT_CASE(3)
+  }
+#undef RR_GEMM_SPLIT_CASE
   switch (epilogue) {
     RR_GEMM_CASE(EPI_BIAS_BF16)
     RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
@@ -1409,6 +1547,15 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
   return 0;
 }
 
+std::atomic<int> g_resid_split{1};       // rr_set_tuning("resid_split")
+extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return 0; }
+// The shape heuristic of rr_launch_gemm_fold, for callers that must know beforehand whether the split residual stream
+// is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
+bool rr_gemm_split_ok(int M, int N) {
+  if (!g_resid_split.load() || g_variant.load() >= 0 || !g_persistent || getenv("RR_GEMM_VARIANT")) return false;
+  return (long)((M + 255) / 256) * ((N + 255) / 256) >= 512 && !(N & 7);
+}
+
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
                           const float* resid, int ldr, void* C, int ldc, int M, int N, int Kd,
                           int epilogue, int dt, hipStream_t st) {
@@ -1434,10 +1581,15 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
   if ((fold.in_stats != nullptr) != (fold.csum != nullptr)) return hipErrorInvalidValue;
   if (fold.in_stats && (epilogue == EPI_BIAS_RESID_F32)) return hipErrorInvalidValue;
   const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta, fold.x16, fold.ldx, (float2*)fold.part, fold.nparts,
-                   (const float2*)fold.in_stats, fold.csum, g_resid_touch.load()};
+                   (const float2*)fold.in_stats, fold.csum, g_resid_touch.load(), fold.r_hi, fold.r_lo, fold.ld16, fold.lo_out};
+  const bool split = fold.r_hi || fold.r_lo || fold.lo_out;
+  if (split) {
+    if (epilogue != EPI_BIAS_RESID_F32 || (fold.r_hi == nullptr) != (fold.r_lo == nullptr) || (fold.ld16 & 3)) return hipErrorInvalidValue;
+    if (!fold.x16 || fold.ldx != fold.ld16 || (fold.ldx & 7) || (N & 7)) return hipErrorInvalidValue;   // the hi half is the x16 rows; 16-byte chunks of 8
+  }
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;
-  if (epilogue == EPI_BIAS_RESID_F32 && (!resid || (ldr & 3))) return hipErrorInvalidValue;
+  if (epilogue == EPI_BIAS_RESID_F32 && !fold.r_hi && (!resid || (ldr & 3))) return hipErrorInvalidValue;
   static std::once_flag env_once;
   std::call_once(env_once, [] {
     const char* e = getenv("RR_GEMM_VARIANT");
@@ -1454,6 +1606,7 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     if (v == 0) v = 20;
     else if (v != 10 && v != 12 && v != 14 && v != 20) return hipErrorInvalidValue;
   }
+  if (split && v != 14) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);

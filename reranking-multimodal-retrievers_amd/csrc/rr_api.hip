@@ -667,6 +667,7 @@ extern "C" int rr_set_gemm_persistent(int on);
 extern "C" int rr_set_resid_touch(int on);
 extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
+extern "C" int rr_set_resid_split(int on);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
 
 // Where a layer's residual comes from: either materialised fp32 rows (after an embedding LayerNorm), or the previous
@@ -676,6 +677,9 @@ struct ResidSrc {
   const float* stats;   // nullptr = x holds the residual itself
   const float* g;
   const float* b;
+  // split residual stream (GemmFold in rr_common.h): the rows as hi (16-bit operand rows) + lo (fp16) instead of fp32 x
+  const bf16_t* hi = nullptr;
+  const bf16_t* lo = nullptr;
 };
 
 #define RR_GEMM_LN(m, st, A, lda, W, bias, rs, C, ldc, M, N, K, outb)                                            \
@@ -684,7 +688,8 @@ struct ResidSrc {
                            EPI_BIAS_RESID_F32, m->dt, st))
 // residual GEMM that also emits the 16-bit copy of its rows (-> x16) and their LayerNorm statistics partials
 #define RR_GEMM_LN_PREP(m, st, A, lda, W, bias, rs, C, ldc, M, N, K, fold)                                         \
-  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, 4.0) + 4.0 * (M) * (N) + 2.0 * (M) * (N),      \
+  RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K),                                                                    \
+         gemm_bytes(M, N, K, (fold).lo_out ? 2.0 : 4.0) + 4.0 * (M) * (N) + 2.0 * (M) * (N),                        \
          rr_launch_gemm_fold(A, lda, W, K, bias, (rs).x, N, (rs).stats, (rs).g, (rs).b, fold, C, ldc, M, N, K,     \
                              EPI_BIAS_RESID_F32, m->dt, st))
 // GEMM whose A operand holds raw pre-LayerNorm rows; the LayerNorm is applied in the epilogue (folded weights)
@@ -768,23 +773,39 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     return RR_OK;
   }
   if (fold) {
+    // Split residual stream (rr_gemm_split_ok: the persistent ring kernel runs these shapes): a pre-LayerNorm row lives
+    // as hi = the 16-bit operand rows in w.h16 + lo = fp16(x - hi) in the memory of w.pre, both updated in place by the
+    // residual epilogues (an element is read and written by the same thread), instead of a third, fp32 copy: 8 instead of
+    // 10 bytes per element through the two HBM-bound epilogues of a layer.  The last layer of a stack writes fp32 rows
+    // (w.pre2) for the LayerNorm kernel that materialises the stack's output.
+    const bool split = rr_gemm_split_ok(rows, Hd);
+    bf16_t* const lo16 = (bf16_t*)w.pre;
     GemmFold fo;
     fo.x16 = w.h16;
     fo.ldx = Hd;
     fo.part = w.lnpart;
     fo.nparts = nparts;
-    RR_GEMM_LN_PREP(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, fo);
+    GemmFold f1 = fo;                      // attention-out: residual = rs, output -> (h16, lo16) or fp32 w.pre
+    f1.r_hi = rs.hi; f1.r_lo = rs.lo; f1.ld16 = Hd;
+    if (split) f1.lo_out = lo16;
+    RR_GEMM_LN_PREP(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, f1);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
            rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st));
     GemmFold fi;
     fi.in_stats = w.stats_a;
     fi.csum = L.c1_f;
     RR_GEMM_FOLDED(m, st, w.h16, Hd, L.w1_f, L.d1_f, fi, w.mid, I, rows, I, Hd, EPI_BIAS_GELU_BF16);
-    const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
-    RR_GEMM_LN_PREP(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, fo);
+    ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
+    if (split) { r1.x = nullptr; r1.hi = w.h16; r1.lo = lo16; }
+    GemmFold f2 = fo;                      // FFN-down: residual = r1, output -> (h16, lo16) in place, or fp32 w.pre2
+    f2.r_hi = r1.hi; f2.r_lo = r1.lo; f2.ld16 = Hd;
+    const bool split_out = split && !want_h32;
+    if (split_out) f2.lo_out = lo16;
+    RR_GEMM_LN_PREP(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, f2);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
            rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st));
     rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
+    if (split_out) { rs.x = nullptr; rs.hi = w.h16; rs.lo = lo16; }
     in_kind = OP_RAW_FOLDED;
     if (want_h32) {   // last layer of a stack: its consumers (CLS heads, 768->128 projection, debug taps) take normalised rows
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
@@ -1599,6 +1620,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
+  if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);
   return RR_ERR_BAD_ARG;
@@ -1688,6 +1710,28 @@ static int rr_op_gemm_resid_lnprep_impl(const uint16_t* A, const uint16_t* W, co
   f.part = part_scratch;
   f.nparts = (N + 127) / 128;
   hipError_t e = rr_launch_gemm_fold(A, Kd, W, Kd, bias, resid, N, nullptr, nullptr, nullptr, f, out_f32, N, M, N, Kd,
+                                     EPI_BIAS_RESID_F32, g_op_dt, (hipStream_t)hip_stream);
+  if (e == hipSuccess) e = rr_launch_ln_finalize(part_scratch, f.nparts, N, eps, M, stats_out, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+/* The residual epilogue on the split stream: residual rows (hi, lo) [+ LayerNorm from (stats, gamma, beta)] in, output rows
+ * (x16_out, lo_out) + statistics out; in-place use (hi_in == x16_out, lo_in == lo_out) is what the forward does. */
+static int rr_op_gemm_resid_split_impl(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in,
+                                       const uint16_t* lo_in, const float* ln_stats, const float* ln_gamma, const float* ln_beta,
+                                       int M, int N, int Kd, float eps, uint16_t* x16_out, uint16_t* lo_out, float* stats_out,
+                                       float* part_scratch, void* hip_stream) {
+  if (!A || !W || !hi_in || !lo_in || !x16_out || !lo_out || !stats_out || !part_scratch) return RR_ERR_BAD_ARG;
+  if (!rr_gemm_split_ok(M, N)) return RR_ERR_UNSUPPORTED;      // shapes the persistent ring kernel does not run
+  GemmFold f;
+  f.x16 = x16_out;
+  f.ldx = N;
+  f.part = part_scratch;
+  f.nparts = (N + 127) / 128;
+  f.r_hi = hi_in;
+  f.r_lo = lo_in;
+  f.ld16 = N;
+  f.lo_out = lo_out;
+  hipError_t e = rr_launch_gemm_fold(A, Kd, W, Kd, bias, nullptr, 0, ln_stats, ln_gamma, ln_beta, f, nullptr, N, M, N, Kd,
                                      EPI_BIAS_RESID_F32, g_op_dt, (hipStream_t)hip_stream);
   if (e == hipSuccess) e = rr_launch_ln_finalize(part_scratch, f.nparts, N, eps, M, stats_out, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
@@ -1785,6 +1829,11 @@ int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float
 int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* bias, const float* resid, int M, int N, int Kd,
                             float eps, float* out_f32, uint16_t* x16_out, float* stats_out, float* part_scratch, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_gemm_resid_lnprep_impl(A, W, bias, resid, M, N, Kd, eps, out_f32, x16_out, stats_out, part_scratch, hip_stream); });
+}
+int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in, const uint16_t* lo_in,
+                           const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
+                           uint16_t* x16_out, uint16_t* lo_out, float* stats_out, float* part_scratch, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_resid_split_impl(A, W, bias, hi_in, lo_in, ln_stats, ln_gamma, ln_beta, M, N, Kd, eps, x16_out, lo_out, stats_out, part_scratch, hip_stream); });
 }
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {

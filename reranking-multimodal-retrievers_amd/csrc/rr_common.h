@@ -40,6 +40,17 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_));   // round-to-nearest-even
   }
 }
+// the two 16-bit values of a packed word back as floats (exact)
+template <int DT>
+__device__ __forceinline__ float2 unpack2(uint32_t u) {
+  if constexpr (DT == 0) {
+    return make_float2(__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u));
+  } else {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    const f16x2_ v = __builtin_bit_cast(f16x2_, u);
+    return make_float2((float)v[0], (float)v[1]);
+  }
+}
 __device__ __forceinline__ uint32_t pack2rt(float lo, float hi, int dt) { return dt ? pack2<1>(lo, hi) : pack2<0>(lo, hi); }
 template <int DT>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -146,7 +157,19 @@ struct GemmFold {
   int nparts = 0;
   const float* in_stats = nullptr;
   const float* csum = nullptr;
+  // split residual stream (persistent ring kernel only; rr_gemm_split_ok): a pre-LayerNorm row x is carried as the pair
+  // hi = 16-bit operand rounding of x (the very `x16` rows the consumer GEMM reads) + lo = fp16(x - hi), 22 (fp16 operands)
+  // or 19 (bf16) significant bits, instead of a third copy in fp32: the residual epilogue moves 8 instead of 10 bytes
+  // per element.  r_hi / r_lo: where THIS launch's residual rows come from (in place of `resid`); lo_out: where the lo
+  // half of the output rows goes (the hi half is x16; the fp32 output C is then not written).  In-place use (r_hi == x16,
+  // r_lo == lo_out) is allowed: an element is read and written by the same thread, read first.
+  const bf16_t* r_hi = nullptr;
+  const bf16_t* r_lo = nullptr;
+  int ld16 = 0;
+  bf16_t* lo_out = nullptr;
 };
+// true when a GEMM with M x N output will run on the kernel that implements the split residual stream
+bool rr_gemm_split_ok(int M, int N);
 hipError_t rr_launch_gemm_ln(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
                              int ldr, const float* ln_stats, const float* ln_gamma, const float* ln_beta, void* C, int ldc,
                              int M, int N, int Kd, int epilogue, int dt, hipStream_t st);

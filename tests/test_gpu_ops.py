@@ -554,3 +554,68 @@ def test_folded_layernorm_halves(lib, M, N, K):
         if epi == 1:
             ln = _gelu(ln)
         assert (o2.float() - ln).abs().max().item() < 0.06
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("with_ln,in_place", [(False, False), (True, True)])
+def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place):
+    """The residual epilogue on the split stream (rr_op_gemm_resid_split): residual rows as hi (operand type) + lo (fp16),
+    optionally LayerNormed on the fly, output rows as (x16, lo) + statistics — against the fp32-stream epilogue
+    (rr_op_gemm_resid_lnprep) fed the SAME residual values.  x16 must be bit-identical, hi + lo must reproduce the fp32
+    rows to 2^-20 relative (fp16 operands: 2^-22), the statistics must agree, and the in-place form (what the forward
+    does) must equal the out-of-place one.  130 048 x 768 = 1 524 tiles: the persistent ring kernel; ragged last row tile."""
+    M, N, K = 130_048 - 77, 768, 128
+    t16 = torch.float16 if dt else torch.bfloat16
+    assert lib.rr_set_op_dtype(dt) == 0
+    try:
+        g = torch.Generator().manual_seed(17 + dt)
+        A = torch.randn(M, K, generator=g).to(t16).cuda()
+        W = (torch.randn(N, K, generator=g) * 0.05).to(t16).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        X = (torch.randn(M, N, generator=g) * 3 + 0.5).cuda()                   # previous sublayer's pre-LayerNorm rows
+        hi = X.to(t16)
+        lo = (X - hi.float()).half()
+        Xs = hi.float() + lo.float()                                             # what the split stream carries
+        assert ((Xs - X).abs() <= X.abs() * 2.0 ** (-19 if dt == 0 else -21) + 1e-7).all()
+        eps = 1e-12
+        nparts = (N + 127) // 128
+        st_in = gamma = beta = None
+        R = Xs
+        if with_ln:
+            mu, var = Xs.double().mean(1), Xs.double().var(1, unbiased=False)
+            st_in = torch.stack([mu, 1 / torch.sqrt(var + eps)], 1).float().contiguous()
+            gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.05 * torch.randn(N, generator=g)).cuda()
+            R = ((Xs - st_in[:, 0:1]) * st_in[:, 1:2] * gamma + beta)           # the kernel's own expression, fp32
+        # fp32-stream epilogue on the same residual values
+        out32 = torch.empty(M, N, device="cuda")
+        x16_ref = torch.empty(M, N, device="cuda", dtype=t16)
+        stats_ref, part = torch.empty(M, 2, device="cuda"), torch.empty(M, nparts, 2, device="cuda")
+        assert lib.rr_op_gemm_resid_lnprep(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.contiguous().data_ptr(), M, N, K, eps,
+                                           out32.data_ptr(), x16_ref.data_ptr(), stats_ref.data_ptr(), part.data_ptr(), _stream()) == 0
+        # split-stream epilogue
+        if in_place:
+            x16, lo_out = hi.clone(), lo.clone()
+            hi_in, lo_in = x16, lo_out
+        else:
+            x16, lo_out = torch.empty_like(hi), torch.empty_like(lo)
+            hi_in, lo_in = hi, lo
+        stats = torch.empty(M, 2, device="cuda")
+        P = lambda t: t.data_ptr() if t is not None else 0
+        assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), hi_in.data_ptr(), lo_in.data_ptr(), P(st_in),
+                                          P(gamma), P(beta), M, N, K, eps, x16.data_ptr(), lo_out.data_ptr(), stats.data_ptr(),
+                                          part.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        if with_ln:     # the reference residual was normalised by torch (no fused multiply-add): 1-ulp differences in fp32 flip a few roundings
+            dx = (x16.float() - x16_ref.float()).abs()
+            assert (dx <= x16_ref.float().abs() * 2.0 ** (-7 if dt == 0 else -10) + 4e-6).all() and (dx > 0).float().mean().item() < 2e-3
+        else:
+            assert torch.equal(x16, x16_ref)
+        got = x16.float() + lo_out.float()
+        rel = 2.0 ** (-19 if dt == 0 else -21)
+        assert ((got - out32).abs() <= out32.abs() * rel + (2e-6 if with_ln else 2e-7)).all(), (got - out32).abs().max().item()
+        assert torch.allclose(stats, stats_ref, rtol=1e-6, atol=1e-6)
+        # shapes the ring kernel does not run are refused, not silently computed some other way
+        assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), hi.data_ptr(), lo.data_ptr(), 0, 0, 0, 512, N, K,
+                                          eps, x16.data_ptr(), lo_out.data_ptr(), stats.data_ptr(), part.data_ptr(), _stream()) == -4
+    finally:
+        lib.rr_set_op_dtype(0)
