@@ -102,6 +102,33 @@ __device__ __forceinline__ void load_bias_chunk(float* const b_all, int* const f
   __syncthreads();
 }
 
+// ---- output rows through a wave-private LDS slice.  The accumulators hold O^T (lane = query row, registers = head
+// dimensions), so storing them directly is 16 instructions of 8 bytes per lane that each touch 64 different rows.  Staged
+// as rows [query][64 d] (144-byte pitch) in the K/V buffers, which are free after the last tile's barrier, a wave writes
+// its rows as 16 bytes per lane, 8 lanes per 128-byte row, 8 rows per instruction (a quarter of the store instructions,
+// whole lines).  Same-wave LDS accesses execute in issue order: no barrier between the two halves.
+constexpr int O_PITCH = 144;
+static_assert(4 * 64 * O_PITCH <= ATTN_LDS_BYTES, "four waves x 64 output rows must fit the workgroup's LDS");
+template <int DT>
+__device__ __forceinline__ void stage_o_rows(char* slice, int row, int h, const f32x16& o0, const f32x16& o1, float inv) {
+  char* rp = slice + row * O_PITCH + 8 * h;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    *(uint2*)(rp + 16 * g) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+    *(uint2*)(rp + 64 + 16 * g) = make_uint2(pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_o_rows(const char* slice, int lane, bf16_t* out_rows /* row 0 of the slice, head offset applied */,
+                                             int out_stride, int rows_valid) {
+#pragma unroll
+  for (int u = 0; u < ROWS / 8; ++u) {
+    const int i = lane + 64 * u, row = i >> 3, c = i & 7;
+    const uint4 v = *(const uint4*)(slice + row * O_PITCH + c * 16);
+    if (row < rows_valid) *(uint4*)(out_rows + (size_t)row * out_stride + c * 8) = v;
+  }
+}
+
 struct AttnArgs {
   const bf16_t* q; int q_stride, q_batch_div, q_batch_off;
   const bf16_t* k; const bf16_t* v; int kv_stride;
@@ -398,15 +425,12 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
   // ---- epilogue: O = O^T / l ; lane writes 4 consecutive d per register group
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (qrow < Tq) {
-    bf16_t* op = a.out + ((size_t)b * Tq + qrow) * a.out_stride + head * 64 + 4 * h;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      *(uint2*)(op + 8 * g) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                         pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-      *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                              pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
-    }
+  {
+    char* const slice = lds + wave * (32 * O_PITCH);        // K/V buffers: free since the last tile's barrier
+    stage_o_rows<DT>(slice, lane & 31, h, o0, o1, inv);
+    const int row0 = qblk * 128 + wave * 32;
+    if (row0 < Tq)
+      store_o_rows<32>(slice, lane, a.out + ((size_t)b * Tq + row0) * a.out_stride + head * 64, a.out_stride, Tq - row0);
   }
   // bound on the row sum = bound on every probability: 2^64 keeps P (bf16) times V finite in fp32; with fp16 operands P
   // itself has to stay below 65504
@@ -613,17 +637,13 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
     const float inv = 1.0f / l_tot;
     bad = bad || !(l_tot < L_MAX);
-    const int qrow = qrow0 + 32 * sb;
-    if (qrow < Tq) {
-      bf16_t* op = a.out + ((size_t)b * Tq + qrow) * a.out_stride + head * 64 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *(uint2*)(op + 8 * g) = make_uint2(pack2<DT>(o[sb][0][4 * g] * inv, o[sb][0][4 * g + 1] * inv),
-                                           pack2<DT>(o[sb][0][4 * g + 2] * inv, o[sb][0][4 * g + 3] * inv));
-        *(uint2*)(op + 32 + 8 * g) = make_uint2(pack2<DT>(o[sb][1][4 * g] * inv, o[sb][1][4 * g + 1] * inv),
-                                                pack2<DT>(o[sb][1][4 * g + 2] * inv, o[sb][1][4 * g + 3] * inv));
-      }
-    }
+    stage_o_rows<DT>(lds + wave * (64 * O_PITCH), 32 * sb + (lane & 31), h, o[sb][0], o[sb][1], inv);   // see stage_o_rows
+  }
+  {
+    const int row0 = qblk * 256 + wave * 64;
+    if (row0 < Tq)
+      store_o_rows<64>(lds + wave * (64 * O_PITCH), lane, a.out + ((size_t)b * Tq + row0) * a.out_stride + head * 64,
+                       a.out_stride, Tq - row0);
   }
   return __syncthreads_or(bad) != 0;
 }
@@ -744,7 +764,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
                                const float* dense_bias, int dense_ld) {
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
-  if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 3)) return hipErrorInvalidValue;
+  if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 7)) return hipErrorInvalidValue;     // 16-byte row chunks everywhere
   if ((long)Tk * kv_stride * 2 >= (1L << 32)) return hipErrorInvalidValue;   // LDS-DMA: 32-bit byte offsets inside one sequence
   const long groups = (long)B * heads, nqb = (Tq + 127) / 128, nblk = ((groups + 7) / 8) * 8 * nqb;
   if (nblk > 0x7fffffffL) return hipErrorInvalidValue;

@@ -1552,7 +1552,8 @@ extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return
 // The shape heuristic of rr_launch_gemm_fold, for callers that must know beforehand whether the split residual stream
 // is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
 bool rr_gemm_split_ok(int M, int N) {
-  if (!g_resid_split.load() || g_variant.load() >= 0 || !g_persistent || getenv("RR_GEMM_VARIANT")) return false;
+  static const bool env_variant = getenv("RR_GEMM_VARIANT") != nullptr;     // read once: an environment override pins a kernel
+  if (!g_resid_split.load() || g_variant.load() >= 0 || !g_persistent || env_variant) return false;
   return (long)((M + 255) / 256) * ((N + 255) / 256) >= 512 && !(N & 7);
 }
 
