@@ -81,20 +81,7 @@ __device__ __forceinline__ float fast_erf(float x) {
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 // CLIP's quick_gelu: x * sigmoid(1.702 x)
 __device__ __forceinline__ float qgelu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
-// erf-GELU in 13 VALU operations: with z = |x|/sqrt(2), t = 1/(1 + p z) and q = 0.5 (a1 t + ... + a5 t^5) exp(-z^2)
-// (Abramowitz-Stegun 7.1.26: Phi(-|x|) = q to 0.75e-7), gelu(x) = max(x, 0) - |x| q.  The 1/sqrt(2), the 0.5 and the
-// log2(e) of the exponential are folded into the constants.
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f((ax * ax) * (-0.5f * 1.4426950408889634f));
-  const float q = (p * t) * e;
-  return fmaf(-ax, q, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()));   // med3(x, 0, +inf) = max(x, 0), one op
-}
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_erf_fast(x); }   // rr_common.h
 
 // Residual taken from a not-yet-normalised row: r = LayerNorm(x) recomputed on the fly from the row statistics the
 // LN kernel left behind ((x - mean) * rstd * gamma + beta, the very expression of elementwise.hip:ln_store).  This

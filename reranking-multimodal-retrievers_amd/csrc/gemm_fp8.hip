@@ -32,16 +32,7 @@ constexpr int BKB = 128;     // K-tile: 128 bytes = 128 fp8 per row
 template <int N>
 __device__ __forceinline__ void wait_vmcnt8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ float gelu13(float x) {   // erf-GELU, the 13-operation form of gemm_bf16.hip:gelu_fast
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f((ax * ax) * (-0.5f * 1.4426950408889634f));
-  return fmaf(-ax, (p * t) * e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()));
-}
+__device__ __forceinline__ float gelu13(float x) { return gelu_erf_fast(x); }   // rr_common.h (the name is historical)
 
 // EPI: 0 = 16bit(acc*s + b), 1 = 16bit(gelu(acc*s + b)), 2 = f32(acc*s + b);  s = scale * row_scale[m] * col_scale[n]
 // (row_scale / col_scale may be null = 1)

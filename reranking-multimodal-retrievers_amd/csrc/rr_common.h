@@ -63,6 +63,25 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// erf-GELU, gelu(x) = max(x, 0) - z Phi(-z) with z = min(|x|, 5.7) and log2 Phi(-z) a degree-7 polynomial in z (a weighted
+// Chebyshev fit on [0, 5.7], the weight being z Phi(-z) itself): ten plain VALU operations and ONE transcendental (the
+// exp2) instead of eleven and two (exp2 + rcp) for the Abramowitz-Stegun 7.1.26 form used before — the GELU runs exposed
+// in the FFN-up epilogue, 128 values per lane and tile.  |gelu - exact| <= 4.8e-7 over [-12, 12] evaluated in fp32
+// (2.1e-7 before), relative error <= 3.4e-5 wherever |gelu| >= 1e-3: three orders below the 16-bit rounding of the output.
+// Beyond |x| = 5.7 the neglected term is below 6e-8.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fminf(fabsf(x), 5.7f);
+  float p = -1.403277905e-06f;
+  p = fmaf(p, z, 5.490869060e-05f);
+  p = fmaf(p, z, -8.929630618e-04f);
+  p = fmaf(p, z, 8.417915996e-03f);
+  p = fmaf(p, z, -5.388785911e-02f);
+  p = fmaf(p, z, -4.584285712e-01f);
+  p = fmaf(p, z, -1.151314700e+00f);
+  p = fmaf(p, z, -9.999805559e-01f);
+  return fmaf(-z, __builtin_amdgcn_exp2f(p), __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()));   // med3(x, 0, +inf) = max(x, 0)
+}
+
 // LDS byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64 x bf16] tile image
 // (128-byte rows).  XOR with (row>>1)&7 keeps every ds_read_b128 lane group (16 rows of one
 // chunk column, cdna_hip_programming.md §2 / T2) on 16 distinct 16-byte slots of the
