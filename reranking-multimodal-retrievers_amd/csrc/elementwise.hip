@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256) void layernorm_q8_kernel(const float* __restri
   const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / scale;
   if (lane == 0) row_scale[row] = scale;
-  uint32_t* orow = (uint32_t*)(o8 + (size_t)row * cols);
+  // A lane's four codes of column group c4 are one dword; stored directly that is 4 bytes per lane and instruction.  The
+  // row is gathered in a wave-private LDS line instead and leaves as 16 bytes per lane (same-wave LDS accesses execute in
+  // issue order: no barrier).
+  __shared__ __attribute__((aligned(16))) uint32_t line[4][64 * MAX_V4];
+  uint32_t* const ln_ = line[threadIdx.x >> 6];
 #pragma unroll
   for (int i = 0; i < MAX_V4; ++i) {
     const int c4 = lane + 64 * i;
@@ -134,7 +138,21 @@ __global__ __launch_bounds__(256) void layernorm_q8_kernel(const float* __restri
       int w = 0;
       w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
       w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-      orow[c4] = (uint32_t)w;
+      ln_[c4] = (uint32_t)w;
+    }
+  }
+  uint8_t* const orow = o8 + (size_t)row * cols;
+  const bool wide = ((cols & 15) == 0) && ((((size_t)orow) & 15) == 0);
+#pragma unroll
+  for (int j = 0; j < (MAX_V4 + 3) / 4; ++j) {
+    const int d0 = (lane + 64 * j) * 4;                 // first dword of this lane's 16-byte chunk
+    if (d0 >= n4) continue;
+    if (wide) {
+      *(uint4*)(orow + (size_t)d0 * 4) = *(const uint4*)(ln_ + d0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (d0 + k < n4) ((uint32_t*)orow)[d0 + k] = ln_[d0 + k];
     }
   }
 }

@@ -160,9 +160,13 @@ __device__ __forceinline__ void fold_emit(const LnResid& ln, float4 f, bool vali
   if (valid && (threadIdx.x & 31) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(m, m2);
 }
 // Consumer side: (acc - mean * c) * rstd for 4 consecutive columns of a row with statistics st = (mean, rstd)
-__device__ __forceinline__ f32x4 fold_apply(f32x4 acc, float2 st, float4 cs) {
-  return f32x4{(acc[0] - st.x * cs.x) * st.y, (acc[1] - st.x * cs.y) * st.y, (acc[2] - st.x * cs.z) * st.y,
-               (acc[3] - st.x * cs.w) * st.y};
+// ... with the bias d merged: (acc - mean c) rstd + d = acc rstd + (d - mean rstd c), two fused multiply-adds per element
+// instead of three operations (|mean c| is of the size of the result here, so nothing is lost to cancellation).  Every
+// kernel of this file uses this one form: they stay bit-identical to each other.
+__device__ __forceinline__ f32x4 fold_apply(f32x4 acc, float2 st, float4 cs, float4 bv) {
+  const float ms = -st.x * st.y;
+  return f32x4{fmaf(acc[0], st.y, fmaf(ms, cs.x, bv.x)), fmaf(acc[1], st.y, fmaf(ms, cs.y, bv.y)),
+               fmaf(acc[2], st.y, fmaf(ms, cs.z, bv.z)), fmaf(acc[3], st.y, fmaf(ms, cs.w, bv.w))};
 }
 __device__ __forceinline__ float4 ln_apply(float4 x, const LnResid& ln, int gm, int gn) {
   if (!ln.stats) return x;
@@ -330,9 +334,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
       if (ln.in_stats && gn < N) cs = *(const float4*)(ln.csum + gn);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (ln.in_stats) acc[nt][mt] = fold_apply(acc[nt][mt], fst[mt], cs);
-        float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
-              v3 = acc[nt][mt][3] + bv.w;
+        const f32x4 ab = ln.in_stats ? fold_apply(acc[nt][mt], fst[mt], cs, bv)
+                                     : f32x4{acc[nt][mt][0] + bv.x, acc[nt][mt][1] + bv.y, acc[nt][mt][2] + bv.z, acc[nt][mt][3] + bv.w};
+        float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
         if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
         if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
         if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
@@ -395,9 +399,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
     for (int mt = 0; mt < MT; ++mt) {
       const int gm = m0 + wm * TM + mt * 16 + (lane & 15);
       if (gm >= M) continue;
-      if (ln.in_stats) acc[nt][mt] = fold_apply(acc[nt][mt], fst[mt], cs);
-      float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z,
-            v3 = acc[nt][mt][3] + bv.w;
+      const f32x4 ab = ln.in_stats ? fold_apply(acc[nt][mt], fst[mt], cs, bv)
+                                   : f32x4{acc[nt][mt][0] + bv.x, acc[nt][mt][1] + bv.y, acc[nt][mt][2] + bv.z, acc[nt][mt][3] + bv.w};
+      float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
       if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
@@ -675,10 +679,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
       for (int nt = 0; nt < 2; ++nt) {
         const int gn = n0 + (q & 1) * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
         const float4 cs = gn < N ? *(const float4*)(ln.csum + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bf = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);   // merged here, not added again below
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[q][nt][mt] = fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs);
+        for (int mt = 0; mt < 4; ++mt) acc[q][nt][mt] = fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bf);
       }
   }
+  const bool bias_done = ln.in_stats != nullptr;
   if constexpr (LDS_EPI) {
     constexpr int ES = F32_OUT ? 4 : 2;
     constexpr int PITCH = BN * ES + 16;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int gn = n0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
-        const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = (bias && gn < N && !bias_done) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
@@ -783,7 +789,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
       for (int nt = 0; nt < 2; ++nt) {
         const int gn = n0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
         if (gn >= N) continue;
-        const float4 bv = bias ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = (bias && !bias_done) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int gm = m0 + hA * 128 + wr * 64 + mt * 16 + (lane & 15);
@@ -1121,9 +1127,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         if (ln.in_stats && gn < N) cs = *(const float4*)(ln.csum + gn);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          if (ln.in_stats) acc[q][nt][mt] = fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs);
-          float v0 = acc[q][nt][mt][0] + bv.x, v1 = acc[q][nt][mt][1] + bv.y, v2 = acc[q][nt][mt][2] + bv.z,
-                v3 = acc[q][nt][mt][3] + bv.w;
+          const f32x4 ab = ln.in_stats ? fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bv)
+                                       : f32x4{acc[q][nt][mt][0] + bv.x, acc[q][nt][mt][1] + bv.y, acc[q][nt][mt][2] + bv.z, acc[q][nt][mt][3] + bv.w};
+          float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
           if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
           if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
           if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
