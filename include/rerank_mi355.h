@@ -353,7 +353,7 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
                        float* row_scale, float* stats, void* hip_stream);
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host);
 int rr_set_gemm_variant(int variant);
-int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "resid_split" (default 1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo instead of fp32), "resid_touch" (default 1), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64, 3 = default: 2 where 256-row workgroups pad no more rows than 128-row ones, else 1; any other value restores the default) */
+int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "resid_split" (default 1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo instead of fp32), "resid_touch" (default 1), "attn_pipe" (default 0: software-pipelined tile of the 64-row attention form; measured neutral), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64, 3 = default: 2 where 256-row workgroups pad no more rows than 128-row ones, else 1; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */
