@@ -281,9 +281,13 @@ def test_attention_fixed_reference_forms_are_bitwise_equal(lib):
         for mode in (1, 2):
             assert lib.rr_set_tuning(b"attn_fixed_ref", mode) == 0
             outs.append(_run_attn(lib, q, k, v, bias, heads))
+        # the software-pipelined tile of the 64-row form (rr_set_tuning "attn_pipe") reorders instructions, not arithmetic
+        assert lib.rr_set_tuning(b"attn_pipe", 1) == 0
+        outs.append(_run_attn(lib, q, k, v, bias, heads))
     finally:
         lib.rr_set_tuning(b"attn_fixed_ref", -1)
-    assert torch.equal(outs[0], outs[1])
+        lib.rr_set_tuning(b"attn_pipe", 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert (outs[0] - _attn_ref(q, k, v, bias, heads)).abs().max().item() < 3e-2
 
 
