@@ -221,7 +221,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
 
   // diagnostic build: s_memtime marks per KV tile (read after the tile's barrier), summed per wave
   unsigned long long dg[5] = {0, 0, 0, 0, 0}, tmk[6];
-#define RR_MARK(k) { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
+#define RR_MARK(k) { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tmk[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
   const int nt = (Tk + KT - 1) / KT;
   const bool prio = (a.tuning & 1) != 0;
   RR_LOAD_TILE(0, 0)
