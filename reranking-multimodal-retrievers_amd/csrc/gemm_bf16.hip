@@ -818,7 +818,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 // for 16-bit output, four 64-row passes for fp32), so the 5-6k-cycle cold prologue of every tile but the first hides
 // behind the previous tile's epilogue.  Same main loop, same arithmetic, same results as gemm_kernel_h.
 // SPLIT (EPI_BIAS_RESID_F32 only): bit 0 = the residual rows come as the (hi, lo) pair, bit 1 = the output rows leave as one.
-template <int EPI, int DT, int SPLIT = 0>
+// DIAG (tools/bench_gemm.py --epilogue-timeline): 1 = per-wave s_memtime marks around the sections of the epilogue, summed over the
+// workgroup's tiles; 2 = also the 13 marks per K-tile of the main loop (they cost the loop ~11 %).  0 in every product launch.
+template <int EPI, int DT, int SPLIT = 0, int DIAG = 0>
 __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__ A, int lda,
                                                      const bf16_t* __restrict__ W, int ldw,
                                                      const float* __restrict__ bias,
@@ -826,7 +828,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                      int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
                                                      int stagger_unit) {
-  constexpr bool DIAG = false;
   // row panels per group of the tile order (below): 8 for K <= 1024 (4 when the weight has more than 9 column slices),
   // plain row-major for deeper K where one 256-row activation panel is already 1.5 MB (measured per shape with
   // tools/bench_gemm.py --stagger 50..56: QKV +5 %, FFN-up +3 %, attention-out +2 % over row-major, FFN-down best as is)
@@ -929,19 +930,54 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // BEHIND wins the MFMA pipe, so they advance together instead of the older wave racing ahead to idle at the barrier
 #define RR_PRIO(p) __builtin_amdgcn_s_setprio(p);
 
-  // Folded LayerNorm, consumer side: the (mean, rstd) of this tile's 256 rows (2 KiB = 16 lines) are touched by one
-  // register-free LDS-DMA per tile while the main loop runs, so that the epilogue's statistics loads hit L2 (the dwords
-  // land in LDS beyond the ring, [128 KiB, ...), which nothing reads).  Issued BEFORE the tile's ring refills: an
-  // older operation only makes the counted waits of the loop marginally stricter, never weaker.
-  auto touch_stats = [&](int m0_) {
-    if (!ln.in_stats || !(ln.flags & 1) || wave != 0 || m0_ + 256 > M) return;
-    glds4_so(ln.in_stats + m0_, (uint32_t)((lane & 15) * 128), __builtin_amdgcn_readfirstlane(lds_base + 8 * HALF));
+  // Per-tile epilogue parameters through LDS.  The accumulator arithmetic of the epilogue needs, per lane, the (mean, rstd) of
+  // 8 rows (folded LayerNorm, consumer side) and bias / column sums of 32 columns.  As global loads they sat BEHIND the ten
+  // LDS-DMA pieces of the next tile's prefetch in the wave's in-order vmcnt queue, so the first multiply-add of every tile
+  // waited for 80 KiB of prefetch to land (tools/gemm_epilogue_timeline.py: 5.5-6.8k cycles per tile for 1-2k cycles of
+  // arithmetic).  Now 16 dword LDS-DMA pieces per tile (2 per wave, exact per-dword clamping at ragged edges) bring them
+  // to [152 KiB, 156 KiB) at the START of the tile's main loop — older than every ring refill of the tile, so the loop's
+  // counted waits only get marginally stricter, never weaker — and the epilogue reads them with ds_read (lgkmcnt only).
+  // Layout: +0 stats[256] float2, +2048 bias[256] f32, +3072 csum[256] f32; residual epilogue with the LayerNorm-recompute
+  // (ln.stats): +4096 gamma[256], +5120 beta[256], +6144 (mean, rstd)[256] of the residual rows — 16 more pieces per tile —
+  // so that its passes hold no per-thread gamma/beta registers across the tile and issue no statistics loads beside the
+  // residual rows.  Same values, same arithmetic as before.
+  constexpr int PARAM_OFF = 152 * 1024;
+  auto stage_params = [&](int m0_, int n0_) {
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));     // opaque: the per-lane offsets below are recomputed here (a dozen VALU per tile), not hoisted out of the tile loop and spilled
+    const int lane = lane_;
+    if (ln.in_stats) {
+      const int d = wave * 64 + lane;                                   // dword d of the 256 x float2 block
+      glds4_so(ln.in_stats + m0_, (uint32_t)((min(d >> 1, M - 1 - m0_) * 2 + (d & 1)) * 4),
+               __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + wave * 256));
+    }
+    if (wave < 4) {
+      if (bias) glds4_so(bias + n0_, (uint32_t)(min(wave * 64 + lane, N - 1 - n0_) * 4),
+                         __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 2048 + wave * 256));
+    } else if (ln.csum) {
+      glds4_so(ln.csum + n0_, (uint32_t)(min((wave - 4) * 64 + lane, N - 1 - n0_) * 4),
+               __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 3072 + (wave - 4) * 256));
+    }
+    if (EPI == EPI_BIAS_RESID_F32 && ln.stats) {
+      const int d = wave * 64 + lane;
+      glds4_so(ln.stats + m0_, (uint32_t)((min(d >> 1, M - 1 - m0_) * 2 + (d & 1)) * 4),
+               __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 6144 + wave * 256));
+      glds4_so((wave < 4 ? ln.gamma : ln.beta) + n0_, (uint32_t)(min((wave & 3) * 64 + lane, N - 1 - n0_) * 4),
+               __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 4096 + (wave >> 2) * 1024 + (wave & 3) * 256));
+    }
   };
   // ---- first output tile: cold prologue, half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3})
-  touch_stats(m0);
+  stage_params(m0, n0);
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
   if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
   bool first_tile = true;
+  // epilogue timeline (DIAG): ep[0] main loop, [1] next-tile setup + prefetch issue, [2] accumulator arithmetic, then per pass
+  // summed: [3] staging writes, [4] prefetch confirm + touch, [5] barrier, [6] residual load issue, [7] residual load wait,
+  // [8] stream-out body, [9] closing barrier; [10] tile tail, [11] tiles
+  unsigned long long ep[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, em0 = 0, em1 = 0;
+#define EP_MARK(var) { if constexpr (DIAG != 0) { RR_SBAR(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); RR_SBAR(); } }
+#define EP_ADD(slot) { if constexpr (DIAG != 0) { EP_MARK(em1) ep[slot] += em1 - em0; em0 = em1; } }
+  EP_MARK(em0)
   for (;;) {                                                // one iteration per output tile of this workgroup
   // First output tile: all of K-tile 0 landed (my pieces; the cold queue is [g0..g6], vmcnt(4) leaves g5, g6), then the
   // barrier.  Later tiles: every wave confirmed its pieces of the prefetched g0..g4 inside the previous epilogue — before
@@ -966,10 +1002,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // Diagnostic build (DIAG): per-wave s_memtime marks inside every phase, summed over the loop and written to
   // stamps[block][8 + wave*8 + k]; the marks are read only after the phase's own lgkmcnt(0), so they add no wait.
   unsigned long long dg[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tmk[9];
-#define RR_MARK(k) { if constexpr (DIAG) { RR_SBAR(); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); RR_SBAR(); } }
+#define RR_MARK(k) { if constexpr (DIAG == 2) { RR_SBAR(); asm volatile("s_memtime %0" : "=s"(tmk[k]) :: "memory"); RR_SBAR(); } }
 #define RR_ACC(base, n)                                                                       \
   {                                                                                           \
-    if constexpr (DIAG) {                                                                     \
+    if constexpr (DIAG == 2) {                                                                \
       _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_) dg[(base) + k_] += tmk[k_ + 1] - tmk[k_]; \
     }                                                                                         \
   }
@@ -1066,12 +1102,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1])); \
     RR_ACC(8, 5)                                                                                           \
   }
-  const bool no_dma = DIAG && stagger_unit == 61;            // diagnostic: main loop without refills (wrong results)
+  const bool no_dma = DIAG == 2 && stagger_unit == 61;            // diagnostic: main loop without refills (wrong results)
   int t = 0;
   for (; t < nk - 2; ++t) RR_TILE(1)
   for (; t < nk; ++t) RR_TILE(0)
 #undef RR_TILE
-  if constexpr (DIAG) {
+  if constexpr (DIAG == 2) {
     if (stamps && lane == 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       unsigned long long* o = stamps + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 16;
@@ -1083,6 +1119,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #undef RR_ACC
   wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
   if (first_tile) stamp(stamps, 2);
+  EP_ADD(0)
 
   // ---- next output tile of this workgroup: request its first five half-tiles into ring slots 0-4 now (every slot has
   // been free since the last barrier of the main loop); the epilogue below works in the upper LDS half only
@@ -1095,6 +1132,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
     if (nk > 1) RR_DMA(1, 0)
   }
+  EP_ADD(1)
 
   // ---- epilogue of tile (cm0, cn0), staged through the UPPER LDS half [5 * HALF, 160 KiB): 16-bit output in two 128-row
   // passes (pass = hA), fp32 in four 64-row passes (pass = 2*hA + wr: one wave row group at a time)
@@ -1107,6 +1145,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     constexpr int ROWS = F32_OUT ? 64 : 128;
     static_assert(ROWS * PITCH <= 5 * HALF, "staging image must fit above the five prefetch slots");
     char* const stg = lds + 5 * HALF;
+    // The epilogue's per-lane addresses are recomputed from an OPAQUE thread index once per tile (a few dozen VALU): left
+    // visible, hipcc hoists them out of the tile loop as loop invariants, keeps them live across the main loop at 256
+    // VGPRs and spills them — and a scratch reload is a vector-memory operation that queues behind the prefetch DMA.
+    int tid_o_ = tid;
+    asm volatile("" : "+v"(tid_o_));
+    const int tid = tid_o_, lane = tid_o_ & 63;
     // folded LayerNorm, consumer side: A held raw pre-LayerNorm rows; (mean, rstd) of the 8 rows this lane owns
     float2 fst[2][4];
     if (ln.in_stats) {
@@ -1114,17 +1158,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-          fst[hA][mt] = ln.in_stats[min(cm0 + hA * 128 + wr * 64 + mt * 16 + (lane & 15), M - 1)];
+          fst[hA][mt] = *(const float2*)(lds + PARAM_OFF + (hA * 128 + wr * 64 + mt * 16 + (lane & 15)) * 8);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int hB = q & 1;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const int gn = cn0 + hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
-        const float4 bv = (bias && gn < N) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tn_ = hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4, gn = cn0 + tn_;
+        const float4 bv = (bias && gn < N) ? *(const float4*)(lds + PARAM_OFF + 2048 + tn_ * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ln.in_stats && gn < N) cs = *(const float4*)(ln.csum + gn);
+        if (ln.in_stats && gn < N) cs = *(const float4*)(lds + PARAM_OFF + 3072 + tn_ * 4);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 ab = ln.in_stats ? fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bv)
@@ -1137,13 +1181,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         }
       }
     }
+    EP_ADD(2)
     const int my_col = (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0) ? cn0 + (tid & 31) * 8 : cn0 + (tid % CPR) * (16 / ES);
-    float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f), lg1 = lg, lb1 = lb;   // lg1 / lb1: split path, columns +4..+7
-    if (EPI == EPI_BIAS_RESID_F32 && ln.stats && my_col < N) {
-      lg = *(const float4*)(ln.gamma + my_col);
-      lb = *(const float4*)(ln.beta + my_col);
-      if constexpr (SPLIT != 0) { lg1 = *(const float4*)(ln.gamma + my_col + 4); lb1 = *(const float4*)(ln.beta + my_col + 4); }
-    }
+    // gamma / beta of this thread's columns: from the parameter block, re-read in every pass (two or four ds_read_b128)
+    auto load_gb = [&](float4& lg, float4& lb, float4& lg1, float4& lb1) {
+      lg = make_float4(1.f, 1.f, 1.f, 1.f); lb = make_float4(0.f, 0.f, 0.f, 0.f); lg1 = lg; lb1 = lb;   // lg1 / lb1: split path, columns +4..+7
+      if (EPI == EPI_BIAS_RESID_F32 && ln.stats && my_col < N) {
+        const char* pp = lds + PARAM_OFF + 4096 + (my_col - cn0) * 4;
+        lg = *(const float4*)pp;
+        lb = *(const float4*)(pp + 1024);
+        if constexpr (SPLIT != 0) { lg1 = *(const float4*)(pp + 16); lb1 = *(const float4*)(pp + 1024 + 16); }
+      }
+    };
     // The residual rows of a pass are first touched by a register-free LDS-DMA, one 128-byte line per thread (64 rows x
     // 1 KiB = 512 lines), a pass ahead of the loads that consume them: the loads behind the barrier then find their lines
     // in the XCD's L2 instead of paying the HBM latency in front of the first add, four times per tile.  The touched
@@ -1162,7 +1211,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
       }
     };
-    static_assert(!F32_OUT || 5 * HALF + ROWS * PITCH + 8 * 256 <= 160 * 1024, "touch area must fit behind the staging image");
+    static_assert(5 * HALF + ROWS * PITCH + (F32_OUT ? 8 * 256 : 0) <= PARAM_OFF, "staging image + touch area must end below the parameter block");
     touch_resid(0);
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -1187,11 +1236,14 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           }
         }
       }
+      EP_ADD(3)
       // the next tile's prefetched half-tiles: confirm MY pieces now, while the only younger vector-memory operations
       // are this epilogue's own loads (none issued yet in this pass) — not after the stores
       if (pass == 0 && has_next) wait_vmcnt<0>();
       if (pass + 1 < NPASS) touch_resid(pass + 1);
+      EP_ADD(4)
       lds_barrier();
+      EP_ADD(5)
       const int row_base = cm0 + (F32_OUT ? (pass >> 1) * 128 + (pass & 1) * 64 : pass * 128);
       if constexpr (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0) {
         // ---- split residual stream (GemmFold in rr_common.h).  A thread owns 4 chunks of EIGHT columns per pass, so that the
@@ -1218,8 +1270,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             ra[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
-          rst[u] = ln.stats ? ln.stats[min(gm, M - 1)] : make_float2(0.f, 1.f);
+          rst[u] = ln.stats ? *(const float2*)(lds + PARAM_OFF + 6144 + (gm - cm0) * 8) : make_float2(0.f, 1.f);
         }
+        float4 lg, lb, lg1, lb1;
+        load_gb(lg, lb, lg1, lb1);
+        EP_ADD(6)
+        if constexpr (DIAG != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        EP_ADD(7)
 #pragma unroll
         for (int u = 0; u < UN8; ++u) {
           const int r = (tid >> 5) + u * 16, gm = row_base + r;
@@ -1287,6 +1344,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       static_assert(512 % CPR == 0 && ROWS * CPR == 512 * UNR, "one batch per pass; a wave must not straddle rows");
       float4 rv[UNR];
       if (EPI == EPI_BIAS_RESID_F32) {
+        float4 lg, lb, lg1, lb1;
+        load_gb(lg, lb, lg1, lb1);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
@@ -1294,8 +1353,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           const bool ok = gm < M && gcol < N;
           float4 x = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
           if (ln.stats) {
-            const int gm_s = __builtin_amdgcn_readfirstlane(min(gm, M - 1));     // wave-uniform row
-            const float2 st2 = ln.stats[gm_s];
+            const float2 st2 = *(const float2*)(lds + PARAM_OFF + 6144 + (gm - cm0) * 8);   // (rows beyond M were clamped to M - 1 by the DMA)
             x = make_float4((x.x - st2.x) * st2.y * lg.x + lb.x, (x.y - st2.x) * st2.y * lg.y + lb.y,
                             (x.z - st2.x) * st2.y * lg.z + lb.z, (x.w - st2.x) * st2.y * lg.w + lb.w);
           }
@@ -1323,15 +1381,27 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         if (EPI == EPI_BIAS_RESID_F32) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
       }
       }
+      EP_ADD(8)
       lds_barrier();                                       // staging image consumed (next pass / next tile may overwrite it)
+      EP_ADD(9)
     }
   }
   if (first_tile) stamp(stamps, 3);
   first_tile = false;
+  if constexpr (DIAG != 0) ep[11] += 1;
   if (!has_next) break;
-  touch_stats(m0);                                          // (LDS beyond the ring is free again: the staging image is consumed)
+  stage_params(m0, n0);                                     // the NEXT tile's (this tile's epilogue has read its own)
   if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) }                 // slots 5, 6 were under the staging image until now
+  EP_ADD(10)
   }   // output tiles
+  if constexpr (DIAG != 0) {
+    if (stamps && lane == 0) {
+      unsigned long long* o = stamps + (size_t)gridDim.x * 8 + (size_t)gridDim.x * 128 + ((size_t)blockIdx.x * 8 + wave) * 16;
+      for (int k = 0; k < 12; ++k) o[k] = ep[k];
+    }
+  }
+#undef EP_MARK
+#undef EP_ADD
 #undef RR_SETUP_SRC
 #undef RR_DMA
 #undef RR_BLK
@@ -1429,6 +1499,34 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   return hipGetLastError();
 }
 
+// diagnostic build of the persistent kernel (variant 15, tools/bench_gemm.py --epilogue-timeline): the production forms only
+template <int DT>
+hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
+                          int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
+  if (N & 7) return hipErrorInvalidValue;
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
+  const int n_cu = device_cus();
+  if (n_cu < 8 || nwg < n_cu) return hipErrorInvalidValue;
+  constexpr int lds_bytes = 160 * 1024;
+  dim3 grid(n_cu), block(512);
+  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
+#define RR_DIAG_LAUNCH(E, S)                                                                                              \
+  {                                                                                                                       \
+    auto kern = gemm_kernel_hp<E, DT, S, 1>;                                                                              \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);         \
+    if (e != hipSuccess) return e;                                                                                        \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, tiles_n, nwg, \
+                       g_stamps, ln, 0);                                                                                  \
+    return hipGetLastError();                                                                                             \
+  }
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3)
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0)
+  if (epilogue == EPI_BIAS_BF16 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0)
+  if (epilogue == EPI_BIAS_GELU_BF16 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0)
+#undef RR_DIAG_LAUNCH
+  return hipErrorInvalidValue;
+}
+
 template <bool LDS_EPI, int DT>
 hipError_t launch_h(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
                     int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
@@ -1517,7 +1615,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 14) return -1;
+  if (v < -1 || v > 15) return -1;
   g_variant.store(v);
   return 0;
 }
@@ -1546,7 +1644,7 @@ extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return
 // is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
 bool rr_gemm_split_ok(int M, int N) {
   static const bool env_variant = getenv("RR_GEMM_VARIANT") != nullptr;     // read once: an environment override pins a kernel
-  if (!g_resid_split.load() || g_variant.load() >= 0 || !g_persistent || env_variant) return false;
+  if (!g_resid_split.load() || (g_variant.load() >= 0 && g_variant.load() != 15) || !g_persistent || env_variant) return false;
   return (long)((M + 255) / 256) * ((N + 255) / 256) >= 512 && !(N & 7);
 }
 
@@ -1598,9 +1696,9 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
   }
   if (fold.x16) {   // the producer side of the folded LayerNorm lives in the LDS-staged epilogues only
     if (v == 0) v = 20;
-    else if (v != 10 && v != 12 && v != 14 && v != 20) return hipErrorInvalidValue;
+    else if (v != 10 && v != 12 && v != 14 && v != 15 && v != 20) return hipErrorInvalidValue;
   }
-  if (split && v != 14) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
+  if (split && v != 14 && v != 15) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
@@ -1610,6 +1708,7 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
       case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 14: return launch_hp<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 15: return launch_hp_diag<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       default: return hipErrorInvalidValue;
     }
   }
