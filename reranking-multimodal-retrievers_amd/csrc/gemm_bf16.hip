@@ -820,7 +820,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 // SPLIT (EPI_BIAS_RESID_F32 only): bit 0 = the residual rows come as the (hi, lo) pair, bit 1 = the output rows leave as one.
 // DIAG (tools/bench_gemm.py --epilogue-timeline): 1 = per-wave s_memtime marks around the sections of the epilogue, summed over the
 // workgroup's tiles; 2 = also the 13 marks per K-tile of the main loop (they cost the loop ~11 %).  0 in every product launch.
-template <int EPI, int DT, int SPLIT = 0, int DIAG = 0>
+// FOLD: the folded-LayerNorm consumer form (ln.in_stats / ln.csum given) — a compile-time choice so that the accumulator
+// arithmetic is one straight-line block (as a run-time branch its two arms joined in 128 accumulator phis and spilled).
+template <int EPI, int DT, int SPLIT = 0, int DIAG = 0, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__ A, int lda,
                                                      const bf16_t* __restrict__ W, int ldw,
                                                      const float* __restrict__ bias,
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     int lane_ = lane;
     asm volatile("" : "+v"(lane_));     // opaque: the per-lane offsets below are recomputed here (a dozen VALU per tile), not hoisted out of the tile loop and spilled
     const int lane = lane_;
-    if (ln.in_stats) {
+    if constexpr (FOLD) {
       const int d = wave * 64 + lane;                                   // dword d of the 256 x float2 block
       glds4_so(ln.in_stats + m0_, (uint32_t)((min(d >> 1, M - 1 - m0_) * 2 + (d & 1)) * 4),
                __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + wave * 256));
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     if (wave < 4) {
       if (bias) glds4_so(bias + n0_, (uint32_t)(min(wave * 64 + lane, N - 1 - n0_) * 4),
                          __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 2048 + wave * 256));
-    } else if (ln.csum) {
+    } else if (FOLD) {
       glds4_so(ln.csum + n0_, (uint32_t)(min((wave - 4) * 64 + lane, N - 1 - n0_) * 4),
                __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 3072 + (wave - 4) * 256));
     }
@@ -966,6 +968,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 4096 + (wave >> 2) * 1024 + (wave & 3) * 256));
     }
   };
+  if (!bias) {          // no bias vector: the block reads as zeros for the whole launch (made visible by the cold prologue's barrier)
+    if (tid < 256) *(float*)(lds + PARAM_OFF + 2048 + tid * 4) = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   // ---- first output tile: cold prologue, half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3})
   stage_params(m0, n0);
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
@@ -1151,34 +1157,57 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     int tid_o_ = tid;
     asm volatile("" : "+v"(tid_o_));
     const int tid = tid_o_, lane = tid_o_ & 63;
-    // folded LayerNorm, consumer side: A held raw pre-LayerNorm rows; (mean, rstd) of the 8 rows this lane owns
-    float2 fst[2][4];
-    if (ln.in_stats) {
+    // Accumulator arithmetic.  Which form runs (folded LayerNorm or plain bias) is decided ONCE per tile, and bias / column
+    // sums are read from the parameter block without a column test (the block always holds 256 entries: beyond N the DMA
+    // repeated the last column, whose results are never stored; without a bias the block was zeroed at kernel start).  The
+    // first version tested `ln.in_stats`, `bias` and `gn < N` around every group of four multiply-adds: 100+ scalar
+    // branches and exec-mask regions per tile (3.7-3.9k cycles for ~1k cycles of arithmetic in the epilogue timeline).
+    auto activate = [&](f32x4 ab) -> f32x4 {
+      float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
+      if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
+      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
+      return f32x4{v0, v1, v2, v3};
+    };
+    const char* const pcol = lds + PARAM_OFF + 2048 + (wc * 32 + (lane >> 4) * 4) * 4;     // bias of this lane's first column; csum at +1024
+    // The parameter reads run one (quadrant, column block) step ahead of the arithmetic that consumes them, pinned with
+    // scheduling fences: left free, hipcc hoists all 16 ds_read_b128 (64 registers) to the top of the section, which at
+    // 128 live accumulators spills the main loop's carried registers around it.
+    if constexpr (FOLD) {
+      // folded LayerNorm, consumer side: A held raw pre-LayerNorm rows; (mean, rstd) of the 8 rows this lane owns
+      float2 fst[2][4];
 #pragma unroll
       for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
           fst[hA][mt] = *(const float2*)(lds + PARAM_OFF + (hA * 128 + wr * 64 + mt * 16 + (lane & 15)) * 8);
-    }
+      float4 bv_n = *(const float4*)(pcol), cs_n = *(const float4*)(pcol + 1024);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int hB = q & 1;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int tn_ = hB * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4, gn = cn0 + tn_;
-        const float4 bv = (bias && gn < N) ? *(const float4*)(lds + PARAM_OFF + 2048 + tn_ * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ln.in_stats && gn < N) cs = *(const float4*)(lds + PARAM_OFF + 3072 + tn_ * 4);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 ab = ln.in_stats ? fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bv)
-                                       : f32x4{acc[q][nt][mt][0] + bv.x, acc[q][nt][mt][1] + bv.y, acc[q][nt][mt][2] + bv.z, acc[q][nt][mt][3] + bv.w};
-          float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
-          if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-          if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
-          if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-          acc[q][nt][mt] = f32x4{v0, v1, v2, v3};
+      for (int it = 0; it < 8; ++it) {
+        const int q = it >> 1, nt = it & 1;
+        const float4 bv = bv_n, cs = cs_n;
+        if (it + 1 < 8) {
+          const int o = ((((it + 1) >> 1) & 1) * 128 + ((it + 1) & 1) * 16) * 4;
+          bv_n = *(const float4*)(pcol + o);
+          cs_n = *(const float4*)(pcol + 1024 + o);
         }
+        RR_SBAR();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[q][nt][mt] = activate(fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bv));
+        RR_SBAR();
+      }
+    } else {
+      float4 bv_n = *(const float4*)(pcol);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = it >> 1, nt = it & 1;
+        const float4 bv = bv_n;
+        if (it + 1 < 8) bv_n = *(const float4*)(pcol + ((((it + 1) >> 1) & 1) * 128 + ((it + 1) & 1) * 16) * 4);
+        RR_SBAR();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[q][nt][mt] = activate(f32x4{acc[q][nt][mt][0] + bv.x, acc[q][nt][mt][1] + bv.y, acc[q][nt][mt][2] + bv.z, acc[q][nt][mt][3] + bv.w});
+        RR_SBAR();
       }
     }
     EP_ADD(2)
@@ -1342,13 +1371,39 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       // add/store (a wave keeps one row per step: its LayerNorm statistics are a scalar load)
       constexpr int UNR = 8;
       static_assert(512 % CPR == 0 && ROWS * CPR == 512 * UNR, "one batch per pass; a wave must not straddle rows");
-      float4 rv[UNR];
-      if (EPI == EPI_BIAS_RESID_F32) {
-        float4 lg, lb, lg1, lb1;
-        load_gb(lg, lb, lg1, lb1);
+      if constexpr (EPI != EPI_BIAS_RESID_F32) {
+        // all eight staged chunks are read first (unconditionally: the image always holds the whole pass), then stored:
+        // read-wait-store per chunk exposed one LDS latency eight times per pass
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
+        for (int h = 0; h < 2; ++h) {
+          uint4 sv[UNR / 2];
+#pragma unroll
+          for (int u = 0; u < UNR / 2; ++u) {
+            const int i = tid + (h * (UNR / 2) + u) * 512, r = i / CPR, c = i - r * CPR;
+            sv[u] = *(const uint4*)(stg + r * PITCH + c * 16);
+          }
+          const bool sw = !F32_OUT && (tid & 256);                // r = tid/32 + 16u: bit 3 of r = bit 8 of tid
+#pragma unroll
+          for (int u = 0; u < UNR / 2; ++u) {
+            const int i = tid + (h * (UNR / 2) + u) * 512, r = i / CPR, c = i - r * CPR;
+            const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
+            const uint4 v = make_uint4(sw ? sv[u].z : sv[u].x, sw ? sv[u].w : sv[u].y, sw ? sv[u].x : sv[u].z, sw ? sv[u].y : sv[u].w);
+            if (gm < M && gcol < N) *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+          }
+          RR_SBAR();
+        }
+      } else {
+      // fp32 residual stream (first / last layer of a stack, fp8 mode): two half-batches of four chunks, the four residual
+      // loads of a half issued before its first add (eight at once spilled 45 registers around the pass at 96 live accumulators)
+      float4 lg, lb, lg1, lb1;
+      load_gb(lg, lb, lg1, lb1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        constexpr int UH = UNR / 2;
+        float4 rv[UH];
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          const int i = tid + (h * UH + u) * 512, r = i / CPR, c = i - r * CPR;
           const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
           const bool ok = gm < M && gcol < N;
           float4 x = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1359,26 +1414,23 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           }
           rv[u] = x;
         }
-      }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
-        const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
-        const bool ok = gm < M && gcol < N;
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-          uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
-          if (!F32_OUT && (tid & 256)) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/32 + 16u: bit 3 of r = bit 8 of tid
-          if (EPI == EPI_BIAS_RESID_F32) {
-            f = __builtin_bit_cast(float4, v);
+        for (int u = 0; u < UH; ++u) {
+          const int i = tid + (h * UH + u) * 512, r = i / CPR, c = i - r * CPR;
+          const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
+          const bool ok = gm < M && gcol < N;
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) {
+            f = *(const float4*)(stg + r * PITCH + c * 16);
             f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
-            v = __builtin_bit_cast(uint4, f);
+            *(float4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = f;
           }
-          *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+          // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
+          // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)
+          if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N);
         }
-        // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
-        // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)
-        if (EPI == EPI_BIAS_RESID_F32) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
+        RR_SBAR();
+      }
       }
       }
       EP_ADD(8)
@@ -1453,16 +1505,27 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
   unsigned long long* stamps = g_stamps;
-#define RR_GEMM_CASE(E)                                                                                       \
-  case E: {                                                                                                   \
-    auto kern = gemm_kernel_hp<E, DT>;                                                                        \
+#define RR_GEMM_CASE_F(E, F)                                                                                  \
+  {                                                                                                           \
+    auto kern = gemm_kernel_hp<E, DT, 0, 0, F>;                                                               \
     static std::atomic<unsigned long long> attr_mask{0};     /* one bit per device ordinal: the attribute is per device */ \
     {                                                                                                         \
       hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);                                   \
+                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);       \
+  }
+#define RR_GEMM_CASE(E)                                                                                       \
+  case E: {                                                                                                   \
+    if (ln.in_stats) return hipErrorInvalidValue;            /* folded LayerNorm: the three forms below only */ \
+    RR_GEMM_CASE_F(E, false)                                                                                  \
+    break;                                                                                                    \
+  }
+#define RR_GEMM_CASE_FOLD(E)                                                                                  \
+  case E: {                                                                                                   \
+    if (ln.in_stats) RR_GEMM_CASE_F(E, true)                                                                  \
+    else RR_GEMM_CASE_F(E, false)                                                                             \
     break;                                                                                                    \
   }
   const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
@@ -1487,15 +1550,17 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   }
 #undef RR_GEMM_SPLIT_CASE
   switch (epilogue) {
-    RR_GEMM_CASE(EPI_BIAS_BF16)
-    RR_GEMM_CASE(EPI_BIAS_GELU_BF16)
-    RR_GEMM_CASE(EPI_BIAS_F32)
+    RR_GEMM_CASE_FOLD(EPI_BIAS_BF16)
+    RR_GEMM_CASE_FOLD(EPI_BIAS_GELU_BF16)
+    RR_GEMM_CASE_FOLD(EPI_BIAS_F32)
     RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
     RR_GEMM_CASE(EPI_BIAS_RESID_F32)
     RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
     default: return hipErrorInvalidValue;
   }
 #undef RR_GEMM_CASE
+#undef RR_GEMM_CASE_FOLD
+#undef RR_GEMM_CASE_F
   return hipGetLastError();
 }
 
@@ -1510,19 +1575,19 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(n_cu), block(512);
   const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
-#define RR_DIAG_LAUNCH(E, S)                                                                                              \
+#define RR_DIAG_LAUNCH(E, S, F)                                                                                           \
   {                                                                                                                       \
-    auto kern = gemm_kernel_hp<E, DT, S, 1>;                                                                              \
+    auto kern = gemm_kernel_hp<E, DT, S, 1, F>;                                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);         \
     if (e != hipSuccess) return e;                                                                                        \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, tiles_n, nwg, \
                        g_stamps, ln, 0);                                                                                  \
     return hipGetLastError();                                                                                             \
   }
-  if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3)
-  if (epilogue == EPI_BIAS_RESID_F32 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0)
-  if (epilogue == EPI_BIAS_BF16 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0)
-  if (epilogue == EPI_BIAS_GELU_BF16 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0)
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0, false)
+  if (epilogue == EPI_BIAS_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0, true)
+  if (epilogue == EPI_BIAS_GELU_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0, true)
 #undef RR_DIAG_LAUNCH
   return hipErrorInvalidValue;
 }
