@@ -835,6 +835,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // tools/bench_gemm.py --stagger 50..56: QKV +5 %, FFN-up +3 %, attention-out +2 % over row-major, FFN-down best as is)
   const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50))      // A/B: 2..64
                     : (stagger_unit == 56 || Kd > 1024) ? 1 : (tiles_n > 9 ? 4 : 8);
+  // De-synchronise the XCDs (rr_set_tuning "gemm_desync"; stagger_unit = 100 + u).  All workgroups of a persistent launch start
+  // together and every tile costs the same, so the 256 CUs run their main loops (HBM nearly idle) and then their epilogues
+  // (HBM saturated) in LOCKSTEP: tools/gemm_epilogue_timeline.py shows every workgroup inside its epilogue at the same
+  // instant for the whole launch, and the residual epilogue moving its 134 MB per round at 6 TB/s — the HBM roofline —
+  // while the main loops leave the memory idle.  The 32 workgroups of an XCD share operand slices through their L2, which
+  // pulls stragglers back into step (a skew INSIDE the XCD did nothing: r03_a), so the skew is per XCD: the workgroups of
+  // XCD x (blockIdx.x & 7 under round-robin placement; speed only, never correctness) start x * u * 256 cycles late, u
+  // chosen by the host so that the eight XCDs cover a fraction of one tile period.
+  if (stagger_unit >= 100) {
+    const int n = (int)(blockIdx.x & 7) * (stagger_unit - 100);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);          // 4 * 64 cycles
+  }
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1126,6 +1138,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
   if (first_tile) stamp(stamps, 2);
   EP_ADD(0)
+  // DIAG: wall-clock (100 MHz s_memrealtime) of the start and end of the first 32 epilogues of every workgroup, to see
+  // whether the CUs run their epilogues in lockstep (stamps + grid * (8 + 256) + block * 64 + 2 * tile)
+  if constexpr (DIAG != 0) {
+    if (stamps && tid == 0 && ep[11] < 32)
+      stamps[(size_t)gridDim.x * 264 + (size_t)blockIdx.x * 64 + 2 * ep[11]] = __builtin_amdgcn_s_memrealtime();
+  }
 
   // ---- next output tile of this workgroup: request its first five half-tiles into ring slots 0-4 now (every slot has
   // been free since the last barrier of the main loop); the epilogue below works in the upper LDS half only
@@ -1242,6 +1260,35 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     };
     static_assert(5 * HALF + ROWS * PITCH + (F32_OUT ? 8 * 256 : 0) <= PARAM_OFF, "staging image + touch area must end below the parameter block");
     touch_resid(0);
+    // ---- split residual stream: the residual rows of pass p + 1 are requested at the END of pass p's body, into the registers
+    // pass p has just consumed, so that their latency runs under the closing barrier, the next staging writes and the barrier
+    // behind them instead of in front of the first add of every pass (epilogue timeline: load issue + wait were 40 % of the
+    // residual epilogue).  Pass 0's are requested here.  In-place use stays safe: a pass reads and writes only its own rows.
+    constexpr int UN8 = 4;
+    const int c8 = tid & 31, gcol8 = cn0 + c8 * 8;
+    const bool col_ok8 = gcol8 < N;                                   // N % 8 == 0: a chunk is inside or outside as a whole
+    constexpr bool SPLIT_EPI = (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0);
+    uint4 rh[SPLIT_EPI ? UN8 : 1], rl[SPLIT_EPI ? UN8 : 1];
+    float4 ra[(SPLIT_EPI && !(SPLIT & 1)) ? UN8 : 1], rb[(SPLIT_EPI && !(SPLIT & 1)) ? UN8 : 1];
+    auto issue_resid = [&](int pass_) {
+      if constexpr (SPLIT_EPI) {
+        const int rbase_ = cm0 + (pass_ >> 1) * 128 + (pass_ & 1) * 64;
+#pragma unroll
+        for (int u = 0; u < UN8; ++u) {
+          const int gm = rbase_ + (tid >> 5) + u * 16;
+          const bool ok = gm < M && col_ok8;
+          if constexpr ((SPLIT & 1) != 0) {
+            rh[u] = ok ? *(const uint4*)(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            rl[u] = ok ? *(const uint4*)(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+          } else {
+            ra[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    };
+    issue_resid(0);
+    EP_ADD(6)
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1281,29 +1328,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         // two rows per step (lanes 0-31 / 32-63), a 128-column group is one DPP row of 16 lanes.  The staging image keeps
         // the even 16-byte chunks of a row in its first 512 bytes and the odd ones in the second, so that the two reads
         // of a lane are each 16 consecutive bytes per lane across a 16-lane group (conflict-free).
-        constexpr int UN8 = 4;
         static_assert(ROWS * 32 == 512 * UN8, "one batch of four 8-column chunks per thread and pass");
-        const int c8 = tid & 31, gcol = cn0 + c8 * 8;
-        const bool col_ok = gcol < N;                                     // N % 8 == 0: a chunk is inside or outside as a whole
-        uint4 rh[UN8], rl[UN8];
-        float4 ra[(SPLIT & 1) ? 1 : UN8], rb[(SPLIT & 1) ? 1 : UN8];
+        const int gcol = gcol8;
+        const bool col_ok = col_ok8;
         float2 rst[UN8];
 #pragma unroll
         for (int u = 0; u < UN8; ++u) {
-          const int r = (tid >> 5) + u * 16, gm = row_base + r;
-          const bool ok = gm < M && col_ok;
-          if constexpr ((SPLIT & 1) != 0) {
-            rh[u] = ok ? *(const uint4*)(ln.r_hi + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
-            rl[u] = ok ? *(const uint4*)(ln.r_lo + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
-          } else {
-            ra[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          const int gm = row_base + (tid >> 5) + u * 16;
           rst[u] = ln.stats ? *(const float2*)(lds + PARAM_OFF + 6144 + (gm - cm0) * 8) : make_float2(0.f, 1.f);
         }
         float4 lg, lb, lg1, lb1;
         load_gb(lg, lb, lg1, lb1);
-        EP_ADD(6)
         if constexpr (DIAG != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         EP_ADD(7)
 #pragma unroll
@@ -1366,6 +1401,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           const float m2 = row16_sum(q);
           if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
         }
+        EP_ADD(8)
+        if (pass + 1 < NPASS) issue_resid(pass + 1);
+        EP_ADD(6)
       } else {
       // the whole pass in one batch of 8 sixteen-byte chunks per thread: every residual load is issued before the first
       // add/store (a wave keeps one row per step: its LayerNorm statistics are a scalar load)
@@ -1440,7 +1478,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   }
   if (first_tile) stamp(stamps, 3);
   first_tile = false;
-  if constexpr (DIAG != 0) ep[11] += 1;
+  if constexpr (DIAG != 0) {
+    if (stamps && tid == 0 && ep[11] < 32)
+      stamps[(size_t)gridDim.x * 264 + (size_t)blockIdx.x * 64 + 2 * ep[11] + 1] = __builtin_amdgcn_s_memrealtime();
+    ep[11] += 1;
+  }
   if (!has_next) break;
   stage_params(m0, n0);                                     // the NEXT tile's (this tile's epilogue has read its own)
   if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) }                 // slots 5, 6 were under the staging image until now
@@ -1463,7 +1505,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
-std::atomic<int> g_resid_touch{1};       // rr_set_tuning("resid_touch")
+std::atomic<int> g_resid_touch{0};       // rr_set_tuning("resid_touch"): L2 touch of the next pass's residual rows; off since the rows themselves are requested a pass ahead (r03: 100.8 -> 99.8 ms)
 std::atomic<int> g_variant{-1};          // tuning override (rr_set_gemm_variant / RR_GEMM_VARIANT); -1: shape heuristic
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember per device ordinal where
@@ -1492,6 +1534,16 @@ inline int device_cus() {
 }
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
+std::atomic<int> g_desync{0};             // rr_set_tuning("gemm_desync"): percent of the modelled tile period the eight XCDs are spread over
+// start skew of the persistent kernel, as the kernel's stagger_unit argument (100 + sleeps of 256 cycles per XCD index)
+inline int desync_arg(int Kd, int epilogue, int nwg, int n_cu) {
+  const int pct = g_desync.load();
+  if (pct <= 0 || nwg < 8 * n_cu) return 0;                              // fewer than 8 tiles per CU: the skew would cost more than it spreads
+  const long main_cyc = (long)(Kd / 64) * 2700;                          // measured main loop, cycles per 256x256x64 K-tile
+  const long epi_cyc = epilogue == EPI_BIAS_RESID_F32 ? 30000 : epilogue == EPI_BIAS_GELU_BF16 ? 16000 : 8000;
+  const long u = (main_cyc + epi_cyc) * pct / 100 / 8 / 256;
+  return u > 0 ? 100 + (int)(u > 1000 ? 1000 : u) : 0;
+}
 int g_persistent = 1;                     // rr_set_tuning("persistent_gemm"): 1 = variant 14 for large problems, 0 = variant 12
 
 // persistent variant: one workgroup per CU (160 KiB of LDS each), grid = number of CUs rounded down to a multiple of 8
@@ -1505,6 +1557,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
   unsigned long long* stamps = g_stamps;
+  const int desync = desync_arg(Kd, epilogue, nwg, n_cu);
 #define RR_GEMM_CASE_F(E, F)                                                                                  \
   {                                                                                                           \
     auto kern = gemm_kernel_hp<E, DT, 0, 0, F>;                                                               \
@@ -1514,7 +1567,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);       \
+                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : desync);       \
   }
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
@@ -1539,7 +1592,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);       \
+                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : desync);       \
     return hipGetLastError();                                                                                 \
   }
   switch (split) {
@@ -1581,7 +1634,7 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);         \
     if (e != hipSuccess) return e;                                                                                        \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, tiles_n, nwg, \
-                       g_stamps, ln, 0);                                                                                  \
+                       g_stamps, ln, desync_arg(Kd, epilogue, nwg, n_cu));                                                                                \
     return hipGetLastError();                                                                                             \
   }
   if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
@@ -1690,6 +1743,11 @@ extern "C" int rr_set_resid_touch(int on) {
 }
 extern "C" int rr_set_gemm_persistent(int on) {
   g_persistent = on != 0;
+  return 0;
+}
+extern "C" int rr_set_gemm_desync(int pct) {
+  if (pct < 0 || pct > 400) return -1;
+  g_desync.store(pct);
   return 0;
 }
 extern "C" int rr_set_gemm_stagger(int unit) {

@@ -24,11 +24,15 @@ ap.add_argument("--pairs", type=int, default=800)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-timeline", action="store_true")
 ap.add_argument("--shapes", default="qkv,attn_out,ffn1,ffn2")
+ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT")
 a = ap.parse_args()
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 M = a.pairs * 512
 assert lib.rr_set_op_dtype(1) == 0
+for kv in a.tuning:
+    k_, v_ = kv.split("=")
+    assert lib.rr_set_tuning(k_.encode(), int(v_)) == 0, kv
 g = torch.Generator().manual_seed(0)
 NAMES = ["main loop", "next-tile setup+prefetch issue", "accumulator arithmetic", "staging writes (sum of passes)",
          "prefetch confirm + touch", "barrier after staging", "residual load issue", "residual load wait", "stream-out body",
@@ -84,18 +88,33 @@ for name in a.shapes.split(","):
     if a.no_timeline:
         continue
     grid = 256
-    buf = torch.zeros(grid * 8 + grid * 128 + grid * 128, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(grid * 8 + grid * 128 + grid * 128 + grid * 64, dtype=torch.int64, device="cuda")
     lib.rr_set_gemm_variant(15)
     lib.rr_set_gemm_stamps(buf.data_ptr())
     run()
     torch.cuda.synchronize()
     lib.rr_set_gemm_stamps(0)
-    ep = buf[grid * 8 + grid * 128:].view(grid, 8, 16).double()
+    ep = buf[grid * 8 + grid * 128: grid * 8 + grid * 256].view(grid, 8, 16).double()
     tiles = ep[:, :, 11].clamp(min=1)
     per = ep[:, :, :11] / tiles[:, :, None]            # cycles per tile, [block, wave, section]
     tot = per.sum(-1)
     print(f"   tiles per workgroup {tiles.mean():.2f}; cycles per tile (mean over workgroups and waves): total {tot.mean():.0f}")
     for k in range(11):
         print(f"     {NAMES[k]:34s} {per[:, :, k].mean():8.0f}   by wave " + " ".join(f"{per[:, w, k].mean():7.0f}" for w in range(8)))
+    # lockstep check: wall clock (10 ns ticks) of epilogue start / end per workgroup and tile
+    tl = buf[grid * 264:].view(grid, 32, 2).double()
+    ntl = int(min(tiles.min().item(), 16))
+    t0 = tl[:, 0, 0].min()
+    print("   epilogue phase across the 256 workgroups (us since the earliest first epilogue): tile: start min/median/max | length median")
+    for k in range(ntl):
+        st_, en_ = (tl[:, k, 0] - t0) / 100.0, (tl[:, k, 1] - t0) / 100.0
+        print(f"     tile {k:2d}: start {st_.min():7.1f} {st_.median():7.1f} {st_.max():7.1f} | epilogue {(en_ - st_).median():6.1f} us"
+              + (f" | period {(tl[:, k, 0] - tl[:, k - 1, 0]).median() / 100.0:6.1f} us" if k else ""))
+    # fraction of workgroups inside their epilogue, sampled over the steady part of the launch
+    lo_, hi_ = tl[:, 2, 0].median(), tl[:, ntl - 2, 0].median()
+    grid_t = torch.linspace(lo_.item(), hi_.item(), 400, dtype=torch.float64, device=tl.device)
+    inside = ((tl[:, :ntl, 0].reshape(-1, 1) <= grid_t) & (grid_t < tl[:, :ntl, 1].reshape(-1, 1))).view(grid, ntl, -1).any(1).double().mean(0)
+    print(f"   workgroups inside their epilogue at a time: mean {inside.mean():.2f}  min {inside.min():.2f}  max {inside.max():.2f}  "
+          f"(lockstep: min near 0, max near 1; spread: both near the mean)")
 lib.rr_set_gemm_variant(-1)
 lib.rr_set_op_dtype(0)
