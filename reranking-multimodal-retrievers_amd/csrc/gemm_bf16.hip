@@ -1505,368 +1505,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 
 
 
-// Variant D ("dual"): TWO workgroups of 4 waves per CU (80 KiB of LDS each), each walking 256x128 output tiles.  The point is
-// not the tile but the pairing: a SIMD hosts one wave of each workgroup, the two workgroups drift half a tile apart, and while
-// one runs its epilogue (vector ALU, LDS staging, global stores — no matrix instructions) the other one's main loop has the
-// matrix pipe; in gemm_kernel_hp every wave of the CU is in the same phase, so the matrix pipe idles through every epilogue
-// (tools/gemm_epilogue_timeline.py: 27-55 % of a tile's cycles, bound INSIDE the CU — spreading the CUs in time changed
-// nothing).  Price: 48 KiB of operands per 256x128x64 K-tile instead of 64 KiB per 256x256x64 (1.5x the L2->LDS bytes per
-// FLOP), and a ring that is not a full double buffer.
-//   wave (wr, wc) = (wave >> 1, wave & 1): rows wr*128 + mt*16 + (lane&15), mt < 8; columns wc*64 + nt*16 + (lane>>4)*4 + reg, nt < 4
-//   (128 accumulator registers, 8 + 4 fragments per 32-deep k-step: the same per-wave shape as the 8-wave kernels).
-//   LDS ring: 5 slots of 16 KiB (a half-tile = 128 rows x 128 B, XOR-swizzled).  Half-tile stream g = 3t + {0: A rows 0-127,
-//   1: A rows 128-255, 2: W rows}, slot(g) = g mod 5; with s0 = slot of A0(t) the ring holds
-//     s0: A0(t) -> W(t+1)   s0+1: A1(t) -> A0(t+2)   s0+2: W(t) -> A1(t+2)   s0+3: A0(t+1)   s0+4: A1(t+1)      (mod 5)
-//   K-tile t, per wave: [ds_read k-step 1 fragments of t] [8 MFMA] P: lgkmcnt(0) + barrier — every slot of tile t is free —
-//   [DMA W(t+1)] [8 MFMA] [DMA A0(t+2)] [8 MFMA] [DMA A1(t+2)] [8 MFMA] | [8 MFMA] Q: vmcnt(8) + barrier — W(t+1) landed (the A
-//   halves of t+1 were requested a tile earlier) — [ds_read k-step 0 fragments of t+1] [24 MFMA] lgkmcnt(0).
-//   The weight half-tile is the one with the short lead (half a K-tile): weights are always L2-resident (250-400 cycles).
-//   RAW: a wave waits for its own DMA pieces (counted vmcnt) before the barrier that precedes their first ds_read.
-//   WAR: a slot is refilled only after the barrier behind the lgkmcnt(0) that retired its last read.
-// Epilogues: the whole 80 KiB are free after the main loop (one barrier), so 16-bit output is staged in ONE pass (256 rows x
-// 272 B) and the split residual stream in two (128 rows x 528 B, pass = wr); parameters come by plain global loads (nothing
-// is in flight in front of them here).  Output values are bit-identical to gemm_kernel_hp: same k order per accumulator,
-// same epilogue expressions.  SPLIT: 3 only (hi/lo in, hi/lo out); FOLD as in gemm_kernel_hp.
-template <int EPI, int DT, int SPLIT = 0, bool FOLD = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_d(const bf16_t* __restrict__ A, int lda,
-                                                       const bf16_t* __restrict__ W, int ldw,
-                                                       const float* __restrict__ bias,
-                                                       void* __restrict__ Cv, int ldc, int M, int N, int Kd,
-                                                       int tiles_n, int nwg, LnResid ln, int group, int skew) {
-  static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 || EPI == EPI_BIAS_QGELU_BF16 ||
-                (EPI == EPI_BIAS_RESID_F32 && SPLIT == 3), "gemm_kernel_d: 16-bit outputs and the split residual stream only");
-  constexpr int BM = 256, BN = 128, HALF = 128 * 128;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  // persistent XCD-aware walk, as gemm_kernel_hp: workgroup (xcd = bid & 7, j = bid >> 3) takes tiles chunk0 + j + i * (grid / 8)
-  const int bid = blockIdx.x, gstep = (int)(gridDim.x >> 3);
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, chunk_n = q8 + (xcd < r8 ? 1 : 0);
-  int li = bid >> 3;
-  if (li >= chunk_n) return;
-  // the second workgroup of a CU (the later half of the grid under in-order dispatch; speed only) starts `skew` x 256 cycles
-  // late so that the pair does not reach its epilogues together
-  if (skew > 0 && li >= (gstep >> 1)) {
-    for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(4);
-  }
-  const int tiles_m = nwg / tiles_n;
-  int m0, n0;
-  auto tile_origin = [&](int gidx, int& m0_, int& n0_) {      // groups of `group` row panels, column-major inside a group
-    const int per_group = group * tiles_n, grp = gidx / per_group, r = gidx - grp * per_group;
-    const int rows = min(group, tiles_m - grp * group);
-    const int tn = r / rows, tm = grp * group + (r - tn * rows);
-    m0_ = tm * BM;
-    n0_ = tn * BN;
-  };
-  tile_origin(chunk0 + li, m0, n0);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  // ---- DMA sources: a half-tile is 16 pieces of 8 rows x 128 B; this wave moves pieces 4*wave .. 4*wave+3.  32-bit byte
-  // offsets from the scalar origin of the current tile's rows (re-based per output tile)
-  uint32_t so_a0[4], so_a1[4], so_b[4];
-  const bf16_t *a_tile, *w_tile;
-#define RR_D_SETUP(m0_, n0_)                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);          /* row inside the half-tile */             \
-    const int c = (lane & 7) ^ ((r >> 1) & 7);                                                          \
-    so_a0[i] = (uint32_t)(((size_t)min(r, M - 1 - (m0_)) * lda + c * 8) * 2);                           \
-    so_a1[i] = (uint32_t)(((size_t)min(128 + r, M - 1 - (m0_)) * lda + c * 8) * 2);                     \
-    so_b[i] = (uint32_t)(((size_t)min(r, N - 1 - (n0_)) * ldw + c * 8) * 2);                            \
-  }                                                                                                     \
-  a_tile = A + (size_t)(m0_) * lda;                                                                     \
-  w_tile = W + (size_t)(n0_) * ldw;
-  RR_D_SETUP(m0, n0)
-  const uint32_t lds_base = lds_addr(lds);
-  const int nk = Kd / BK;
-  // one half-tile (4 pieces of this wave) of K-tile t_ into the slot at byte offset sl_ (wave-uniform)
-#define RR_D_DMA(base_, so_, t_, sl_)                                                                    \
-  {                                                                                                     \
-    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(sl_) + wave * 4096);     \
-    const void* sb_ = (const void*)((base_) + (size_t)(t_) * BK);                                       \
-    glds16_so(sb_, so_[0], dst_);                                                                       \
-    glds16_so(sb_, so_[1], dst_ + 1024);                                                                \
-    glds16_so(sb_, so_[2], dst_ + 2048);                                                                \
-    glds16_so(sb_, so_[3], dst_ + 3072);                                                                \
-  }
-  // ---- fragment addresses inside a slot: the wave's A half-tile holds exactly its 128 rows; its 64 weight rows start at wc*64
-  const int a_off = swz128(lane & 15, lane >> 4);
-  const int b_off = swz128(wc * 64 + (lane & 15), lane >> 4);
-  auto read_a = [&](const char* slot, int ks, bf16x8 (&f)[8]) {
-    const char* b = slot + (ks ? (a_off ^ 64) : a_off);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) f[mt] = *(const bf16x8*)(b + mt * 2048);
-  };
-  auto read_b = [&](const char* slot, int ks, bf16x8 (&f)[4]) {
-    const char* b = slot + (ks ? (b_off ^ 64) : b_off);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) f[nt] = *(const bf16x8*)(b + nt * 2048);
-  };
-
-  f32x4 acc[4][8];          // [nt][mt]; lane: m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg
-  bf16x8 AF0[8], AF1[8], BF0[4], BF1[4];
-#define RR_D_BLK(NT, AF, BF) _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) acc[NT][mt] = mfma16<DT>(BF[NT], AF[mt], acc[NT][mt]);
-#define RR_SBAR() __builtin_amdgcn_sched_barrier(0)
-  auto wrap5 = [](int s) { return s >= 5 ? s - 5 : s; };
-
-  for (;;) {                                                  // one iteration per output tile of this workgroup
-    // ---- cold prologue: g0 A0(0) -> slot 0, g1 A1(0) -> 1, g2 W(0) -> 2, g3 A0(1) -> 3, g4 A1(1) -> 4
-    RR_D_DMA(a_tile, so_a0, 0, 0 * HALF) RR_D_DMA(a_tile, so_a1, 0, 1 * HALF) RR_D_DMA(w_tile, so_b, 0, 2 * HALF)
-    if (nk > 1) { RR_D_DMA(a_tile, so_a0, 1, 3 * HALF) RR_D_DMA(a_tile, so_a1, 1, 4 * HALF) }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nk > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    read_a(lds + (wr ? 1 : 0) * HALF, 0, AF0);
-    read_b(lds + 2 * HALF, 0, BF0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(AF0[4]), "+v"(AF0[5]), "+v"(AF0[6]), "+v"(AF0[7]),
-                 "+v"(BF0[0]), "+v"(BF0[1]), "+v"(BF0[2]), "+v"(BF0[3]));
-    __builtin_amdgcn_s_setprio(2);                            // main loop above the partner workgroup's epilogue
-    int s0 = 0;                                               // slot of A0(t)
-#define RR_D_TILE(STEADY)                                                                                    \
-    {                                                                                                        \
-      const int o0 = s0 * HALF, o1 = wrap5(s0 + 1) * HALF, o2 = wrap5(s0 + 2) * HALF, o3 = wrap5(s0 + 3) * HALF, \
-                o4 = wrap5(s0 + 4) * HALF;                                                                    \
-      const bool d1 = (STEADY) || t + 1 < nk, d2 = (STEADY) || t + 2 < nk;                                    \
-      /* k-step 1 fragments of this tile; first block of k-step 0 */                                         \
-      read_a(lds + (wr ? o1 : o0), 1, AF1);                                                                  \
-      read_b(lds + o2, 1, BF1);                                                                              \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(0, AF0, BF0)                                                                                  \
-      RR_SBAR();                                                                                             \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-      __builtin_amdgcn_s_barrier();                          /* P: every slot of tile t is free */            \
-      RR_SBAR();                                                                                             \
-      if (d1) RR_D_DMA(w_tile, so_b, t + 1, o0)                                                              \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(1, AF0, BF0)                                                                                  \
-      RR_SBAR();                                                                                             \
-      if (d2) RR_D_DMA(a_tile, so_a0, t + 2, o1)                                                             \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(2, AF0, BF0)                                                                                  \
-      RR_SBAR();                                                                                             \
-      if (d2) RR_D_DMA(a_tile, so_a1, t + 2, o2)                                                             \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(3, AF0, BF0)                                                                                  \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(0, AF1, BF1)                                                                                  \
-      RR_SBAR();                                                                                             \
-      if (d1) {                                              /* Q: W(t+1) landed (A0/A1 of t+1 are older) */  \
-        if (STEADY) wait_vmcnt<8>();                                                                         \
-        else if (d2) wait_vmcnt<8>();                                                                        \
-        else wait_vmcnt<0>();                                                                                \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        RR_SBAR();                                                                                           \
-        read_a(lds + (wr ? o4 : o3), 0, AF0);                                                                \
-        read_b(lds + o0, 0, BF0);                                                                            \
-      }                                                                                                      \
-      RR_SBAR();                                                                                             \
-      RR_D_BLK(1, AF1, BF1)                                                                                  \
-      RR_D_BLK(2, AF1, BF1)                                                                                  \
-      RR_D_BLK(3, AF1, BF1)                                                                                  \
-      RR_SBAR();                                                                                             \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-      asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(AF0[4]), "+v"(AF0[5]), "+v"(AF0[6]), \
-                   "+v"(AF0[7]), "+v"(BF0[0]), "+v"(BF0[1]), "+v"(BF0[2]), "+v"(BF0[3]));                     \
-      RR_SBAR();                                                                                             \
-      s0 = wrap5(s0 + 3);                                                                                    \
-    }
-    int t = 0;
-    for (; t < nk - 2; ++t) RR_D_TILE(1)
-    for (; t < nk; ++t) RR_D_TILE(0)
-#undef RR_D_TILE
-    __builtin_amdgcn_s_setprio(0);
-    wait_vmcnt<0>();                                          // (nothing is in flight: every issued half-tile was waited for)
-
-    // ---- epilogue of tile (cm0, cn0); the next tile's origin is computed first (scalar work, off the stores' tail)
-    const int cm0 = m0, cn0 = n0;
-    li += gstep;
-    const bool has_next = li < chunk_n;
-    if (has_next) {
-      tile_origin(chunk0 + li, m0, n0);
-      RR_D_SETUP(m0, n0)
-    }
-    char* const stg = lds;
-    if constexpr (EPI != EPI_BIAS_RESID_F32) {
-      // ---- 16-bit output: bias (+ folded LayerNorm) + activation in registers, one staging pass, 16-byte row-contiguous stores
-      auto activate = [&](f32x4 ab) -> f32x4 {
-        float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
-        if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-        if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
-        if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-        return f32x4{v0, v1, v2, v3};
-      };
-      const int col0 = min(cn0 + wc * 64 + (lane >> 4) * 4, N - 4);      // columns beyond N read the last ones; never stored
-      float4 bv[4], cs[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bv[nt] = cs[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bv[nt] = *(const float4*)(bias + min(col0 + nt * 16, N - 4));
-      }
-      if constexpr (FOLD) {
-        float2 fst[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) fst[mt] = ln.in_stats[min(cm0 + wr * 128 + mt * 16 + (lane & 15), M - 1)];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const float4*)(ln.csum + min(col0 + nt * 16, N - 4));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = activate(fold_apply(acc[nt][mt], fst[mt], cs[nt], bv[nt]));
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 8; ++mt)
-            acc[nt][mt] = activate(f32x4{acc[nt][mt][0] + bv[nt].x, acc[nt][mt][1] + bv[nt].y, acc[nt][mt][2] + bv[nt].z,
-                                         acc[nt][mt][3] + bv[nt].w});
-      }
-      constexpr int PITCH = BN * 2 + 16;                      // 272 B: rows 8 apart share banks -> halves swapped in rows with bit 3 set
-      static_assert(BM * PITCH <= 5 * HALF, "16-bit staging image must fit the ring");
-      __builtin_amdgcn_s_barrier();                           // every wave is done with the ring (its last reads were retired at P)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int cn = wc * 64 + nt * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          const int r = wr * 128 + mt * 16 + (lane & 15);
-          *(uint2*)(stg + r * PITCH + ((cn * 2) ^ (lane & 8))) =
-              make_uint2(pack2<DT>(acc[nt][mt][0], acc[nt][mt][1]), pack2<DT>(acc[nt][mt][2], acc[nt][mt][3]));
-        }
-      }
-      lds_barrier();
-      const int c = tid & 15, gcol = cn0 + c * 8;
-      const bool sw = tid & 128;                              // row = tid/16 + 16u: bit 3 of the row = bit 7 of tid
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint4 sv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sv[u] = *(const uint4*)(stg + ((tid >> 4) + (h * 8 + u) * 16) * PITCH + c * 16);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int gm = cm0 + (tid >> 4) + (h * 8 + u) * 16;
-          const uint4 v = make_uint4(sw ? sv[u].z : sv[u].x, sw ? sv[u].w : sv[u].y, sw ? sv[u].x : sv[u].z, sw ? sv[u].y : sv[u].w);
-          if (gm < M && gcol < N) *(uint4*)((bf16_t*)Cv + (size_t)gm * ldc + gcol) = v;
-        }
-        RR_SBAR();
-      }
-      lds_barrier();                                          // staging image consumed: the ring may be refilled
-    } else {
-      // ---- split residual stream (GemmFold): x = hi + lo [LayerNorm-recomputed] + acc + bias -> (x16, lo_out) + statistics partials
-      {
-        const int col0 = min(cn0 + wc * 64 + (lane >> 4) * 4, N - 4);
-        if (bias) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const float4 bvv = *(const float4*)(bias + min(col0 + nt * 16, N - 4));
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-              acc[nt][mt] = f32x4{acc[nt][mt][0] + bvv.x, acc[nt][mt][1] + bvv.y, acc[nt][mt][2] + bvv.z, acc[nt][mt][3] + bvv.w};
-          }
-        }
-      }
-      constexpr int PITCH = BN * 4 + 16;                      // 528 B; a row keeps its even 16-byte chunks in bytes [0,256), the odd ones in [256,512)
-      static_assert(128 * PITCH <= 5 * HALF, "fp32 staging image (128 rows) must fit the ring");
-      const int c8 = tid & 15, gcol = cn0 + c8 * 8;
-      const bool col_ok = gcol < N;                           // N % 8 == 0
-      const int gcc = min(gcol, N - 8);
-      float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f), lg1 = lg, lb1 = lb;
-      if (ln.stats) {
-        lg = *(const float4*)(ln.gamma + gcc); lg1 = *(const float4*)(ln.gamma + gcc + 4);
-        lb = *(const float4*)(ln.beta + gcc);  lb1 = *(const float4*)(ln.beta + gcc + 4);
-      }
-      const int grp = cn0 >> 7;                               // BN = 128: the tile's columns are one statistics group
-      const float rcnt = __builtin_amdgcn_rcpf((float)max(1, min(128, N - cn0)));
-      __builtin_amdgcn_s_barrier();                           // every wave is done with the ring
-      for (int pass = 0; pass < 2; ++pass) {
-        if (wr == pass) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int cn = wc * 64 + nt * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-              *(f32x4*)(stg + (mt * 16 + (lane & 15)) * PITCH + (((cn >> 3) << 4) | (((cn >> 2) & 1) << 8))) = acc[nt][mt];
-          }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                         // 64 rows per batch: four 8-column chunks per thread
-          uint4 rh[4], rl[4];
-          float2 rst[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int gm = cm0 + pass * 128 + h * 64 + (tid >> 4) + u * 16;
-            const bool ok = gm < M && col_ok;
-            rh[u] = ok ? *(const uint4*)(ln.r_hi + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
-            rl[u] = ok ? *(const uint4*)(ln.r_lo + (size_t)gm * ln.ld16 + gcol) : make_uint4(0u, 0u, 0u, 0u);
-            rst[u] = ln.stats ? ln.stats[min(gm, M - 1)] : make_float2(0.f, 1.f);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int r = h * 64 + (tid >> 4) + u * 16, gm = cm0 + pass * 128 + r;
-            const bool ok = gm < M && col_ok;
-            float x[8];
-            const uint32_t hw[4] = {rh[u].x, rh[u].y, rh[u].z, rh[u].w}, lw[4] = {rl[u].x, rl[u].y, rl[u].z, rl[u].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float2 hh = unpack2<DT>(hw[j]), ll = unpack2<1>(lw[j]);
-              x[2 * j] = hh.x + ll.x; x[2 * j + 1] = hh.y + ll.y;
-            }
-            if (ln.stats) {
-              const float ga[8] = {lg.x, lg.y, lg.z, lg.w, lg1.x, lg1.y, lg1.z, lg1.w};
-              const float ba[8] = {lb.x, lb.y, lb.z, lb.w, lb1.x, lb1.y, lb1.z, lb1.w};
-#pragma unroll
-              for (int j = 0; j < 8; ++j) x[j] = (x[j] - rst[u].x) * rst[u].y * ga[j] + ba[j];
-            }
-            const float4 v0 = *(const float4*)(stg + r * PITCH + c8 * 16);           // columns gcol .. gcol+3
-            const float4 v1 = *(const float4*)(stg + r * PITCH + 256 + c8 * 16);     // columns gcol+4 .. gcol+7
-            float f[8] = {v0.x + x[0], v0.y + x[1], v0.z + x[2], v0.w + x[3], v1.x + x[4], v1.y + x[5], v1.z + x[6], v1.w + x[7]};
-            if (!ok) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) f[j] = 0.f;
-            }
-            uint32_t hi[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
-            if (ok) {
-              *(uint4*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-              uint32_t lo[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float2 hb = unpack2<DT>(hi[j]);
-                lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
-              }
-              *(uint4*)(ln.lo_out + (size_t)gm * ln.ld16 + gcol) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            }
-            // LayerNorm statistics of the 128-column group = the 16 lanes of this DPP row (every lane takes part)
-            const float mg = row16_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) * rcnt;
-            float q = 0.f;
-            if (ok) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
-            }
-            const float m2 = row16_sum(q);
-            if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
-          }
-          RR_SBAR();
-        }
-        lds_barrier();                                        // staging image consumed (next pass / next tile may overwrite it)
-      }
-    }
-    if (!has_next) break;
-  }   // output tiles
-#undef RR_D_SETUP
-#undef RR_D_DMA
-#undef RR_D_BLK
-#undef RR_SBAR
-}
-
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
 std::atomic<int> g_resid_touch{0};       // rr_set_tuning("resid_touch"): L2 touch of the next pass's residual rows; off since the rows themselves are requested a pass ahead (r03: 100.8 -> 99.8 ms)
 std::atomic<int> g_variant{-1};          // tuning override (rr_set_gemm_variant / RR_GEMM_VARIANT); -1: shape heuristic
@@ -1978,58 +1616,6 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
 #undef RR_GEMM_CASE_FOLD
 #undef RR_GEMM_CASE_F
   return hipGetLastError();
-}
-
-std::atomic<int> g_dual{0};               // rr_set_tuning("gemm_dual"): 1 = variant 16 (two workgroups per CU) wherever it is implemented
-std::atomic<int> g_dual_skew{-1};         // rr_set_tuning("gemm_dual_skew"): start skew of a CU's second workgroup in 256-cycle units; -1 = modelled
-
-// dual-workgroup variant: shapes / epilogues it implements
-inline bool dual_ok(int M, int N, int Kd, int epilogue, const LnResid& ln) {
-  if ((N & 7) || Kd < 128) return false;
-  const long tiles = (long)((M + 255) / 256) * ((N + 127) / 128);
-  if (tiles < 2048) return false;                                        // at least four tiles per workgroup (512 workgroups)
-  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
-  if (epilogue == EPI_BIAS_RESID_F32) return split == 3 && ln.x16 != nullptr;
-  if (split) return false;
-  if (ln.in_stats) return epilogue == EPI_BIAS_BF16 || epilogue == EPI_BIAS_GELU_BF16;
-  return epilogue == EPI_BIAS_BF16 || epilogue == EPI_BIAS_GELU_BF16 || epilogue == EPI_BIAS_TANH_BF16 || epilogue == EPI_BIAS_QGELU_BF16;
-}
-template <int DT>
-hipError_t launch_d(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int Kd,
-                    int epilogue, hipStream_t st, LnResid ln) {
-  if (!dual_ok(M, N, Kd, epilogue, ln)) return hipErrorInvalidValue;
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, nwg = tiles_m * tiles_n;
-  const int n_cu = device_cus();
-  if (n_cu < 8) return hipErrorInvalidValue;
-  constexpr int lds_bytes = 80 * 1024;
-  dim3 grid((g_dual_skew.load() == 4096 ? 1 : 2) * n_cu), block(256);     // skew 4096: diagnostic, ONE workgroup per CU
-  const int group = (g_stagger >= 50 && g_stagger <= 55) ? (2 << (g_stagger - 50)) : (g_stagger == 56 || Kd > 1024) ? 1 : 8;
-  // start skew of the second workgroup of each CU: about half of one tile's main loop when the two share the matrix pipe
-  int skew = g_dual_skew.load();
-  if (skew < 0 || skew == 4096) skew = (int)((long)(Kd / 64) * 2048 / 2 / 256);
-#define RR_D_LAUNCH(E, S, F)                                                                                              \
-  {                                                                                                                       \
-    auto kern = gemm_kernel_d<E, DT, S, F>;                                                                               \
-    static std::atomic<unsigned long long> attr_mask{0};                                                                  \
-    {                                                                                                                     \
-      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                            \
-      if (e != hipSuccess) return e;                                                                                      \
-    }                                                                                                                     \
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, C, ldc, M, N, Kd, tiles_n, nwg, ln, group, skew); \
-    return hipGetLastError();                                                                                             \
-  }
-  if (epilogue == EPI_BIAS_RESID_F32) RR_D_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
-  if (ln.in_stats) {
-    if (epilogue == EPI_BIAS_BF16) RR_D_LAUNCH(EPI_BIAS_BF16, 0, true)
-    if (epilogue == EPI_BIAS_GELU_BF16) RR_D_LAUNCH(EPI_BIAS_GELU_BF16, 0, true)
-    return hipErrorInvalidValue;
-  }
-  if (epilogue == EPI_BIAS_BF16) RR_D_LAUNCH(EPI_BIAS_BF16, 0, false)
-  if (epilogue == EPI_BIAS_GELU_BF16) RR_D_LAUNCH(EPI_BIAS_GELU_BF16, 0, false)
-  if (epilogue == EPI_BIAS_TANH_BF16) RR_D_LAUNCH(EPI_BIAS_TANH_BF16, 0, false)
-  if (epilogue == EPI_BIAS_QGELU_BF16) RR_D_LAUNCH(EPI_BIAS_QGELU_BF16, 0, false)
-#undef RR_D_LAUNCH
-  return hipErrorInvalidValue;
 }
 
 // diagnostic build of the persistent kernel (variant 15, tools/bench_gemm.py --epilogue-timeline): the production forms only
@@ -2148,7 +1734,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 16) return -1;
+  if (v < -1 || v > 15) return -1;
   g_variant.store(v);
   return 0;
 }
@@ -2158,12 +1744,6 @@ extern "C" int rr_set_resid_touch(int on) {
 }
 extern "C" int rr_set_gemm_persistent(int on) {
   g_persistent = on != 0;
-  return 0;
-}
-extern "C" int rr_set_gemm_dual(int on) { g_dual.store(on != 0); return 0; }
-extern "C" int rr_set_gemm_dual_skew(int units) {
-  if (units < -1 || units > 4096) return -1;
-  g_dual_skew.store(units);
   return 0;
 }
 extern "C" int rr_set_gemm_desync(int pct) {
@@ -2188,7 +1768,7 @@ extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return
 // is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
 bool rr_gemm_split_ok(int M, int N) {
   static const bool env_variant = getenv("RR_GEMM_VARIANT") != nullptr;     // read once: an environment override pins a kernel
-  if (!g_resid_split.load() || (g_variant.load() >= 0 && g_variant.load() != 15 && g_variant.load() != 16) || !g_persistent || env_variant) return false;
+  if (!g_resid_split.load() || (g_variant.load() >= 0 && g_variant.load() != 15) || !g_persistent || env_variant) return false;
   return (long)((M + 255) / 256) * ((N + 255) / 256) >= 512 && !(N & 7);
 }
 
@@ -2237,15 +1817,12 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     // 128x128 so the grid still fills 256 CUs (measured with tools/bench_gemm.py --stamps, profiles/).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     v = tiles256 >= 512 ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
-    if (v == 14 && g_dual.load() && dual_ok(M, N, Kd, epilogue, ln)) v = 16;   // two workgroups per CU on 256x128 tiles
-  } else if (v == 16 && !dual_ok(M, N, Kd, epilogue, ln)) {
-    v = 14;                                                             // forced variant 16: forms it does not implement run on the persistent ring
   }
   if (fold.x16) {   // the producer side of the folded LayerNorm lives in the LDS-staged epilogues only
     if (v == 0) v = 20;
-    else if (v != 10 && v != 12 && v != 14 && v != 15 && v != 16 && v != 20) return hipErrorInvalidValue;
+    else if (v != 10 && v != 12 && v != 14 && v != 15 && v != 20) return hipErrorInvalidValue;
   }
-  if (split && v != 14 && v != 15 && v != 16) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
+  if (split && v != 14 && v != 15) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
@@ -2256,7 +1833,6 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
       case 12: return launch_h<true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 14: return launch_hp<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 15: return launch_hp_diag<1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-      case 16: return launch_d<1>(A, lda, W, ldw, bias, C, ldc, M, N, Kd, epilogue, st, ln);
       default: return hipErrorInvalidValue;
     }
   }
@@ -2273,7 +1849,6 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     case 12:
     case 13: return launch_h<true, 0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 14: return launch_hp<0>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-    case 16: return launch_d<0>(A, lda, W, ldw, bias, C, ldc, M, N, Kd, epilogue, st, ln);
     default: return hipErrorInvalidValue;
   }
 #undef RR_CFG
