@@ -318,8 +318,10 @@ def main():
                        "queries_per_step": Bq, "pairs_per_step": N, "token_regime": args.regime,
                        "parallelism": (f"REHEARSAL: {world} ranks time-sharing ONE GPU, logits exchanged over gloo through the host; "
                                        "not a scaling measurement") if args.rehearse_one_gpu else
-                                      (f"pairs sharded over {world} GPU(s) ({nranks_seen} rank(s) in the process group), "
-                                       "1 RCCL all-gather of logits/step"),
+                                      (f"pairs sharded over {world} GPU(s) ({nranks_seen} ranks in the process group), "
+                                       "1 RCCL all-gather of logits/step") if distributed else
+                                      "1 GPU, no process group, no collective (the N > 1 legs shard the pairs over ranks with one "
+                                      "RCCL all-gather of logits per step)",
                        "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"},
             "step_ms_device": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
                                "n": len(step_ms), "note": "HIP events around each timed step on the work stream, rank 0"},

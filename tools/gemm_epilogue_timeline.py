@@ -25,11 +25,13 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-timeline", action="store_true")
 ap.add_argument("--shapes", default="qkv,attn_out,ffn1,ffn2")
 ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT")
+ap.add_argument("--stagger", type=int, default=0, help="rr_set_gemm_stagger: 50..55 = tile-order group of 2..64 row panels, 56 = row-major")
 a = ap.parse_args()
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 M = a.pairs * 512
 assert lib.rr_set_op_dtype(1) == 0
+assert lib.rr_set_gemm_stagger(a.stagger) == 0
 for kv in a.tuning:
     k_, v_ = kv.split("=")
     assert lib.rr_set_tuning(k_.encode(), int(v_)) == 0, kv
@@ -38,7 +40,8 @@ NAMES = ["main loop", "next-tile setup+prefetch issue", "accumulator arithmetic"
          "prefetch confirm + touch", "barrier after staging", "residual load issue", "residual load wait", "stream-out body",
          "closing barrier", "tile tail (2 DMA)", "tiles"]
 shapes = {"qkv": (2304, 768, "fold", 0), "attn_out": (768, 768, "split", 0), "ffn1": (3072, 768, "fold", 1),
-          "ffn2": (768, 3072, "split", 0)}
+          "ffn2": (768, 3072, "split", 0), "ffn1_plain": (3072, 768, "fold", 0), "qkv_gelu": (2304, 768, "fold", 1),
+          "n1536_gelu": (1536, 768, "fold", 1), "n4608": (4608, 768, "fold", 0)}
 for name in a.shapes.split(","):
     N, K, kind, epi = shapes[name]
     A = torch.randn(M, K, generator=g).half().cuda()
