@@ -154,7 +154,12 @@ int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len);
  * len_b = Lc (interaction models only).  After rr_reserve no forward of that or a smaller shape allocates, frees or
  * synchronises, which makes the forward capturable into a hipGraph; without it the first forward of a larger shape
  * grows the buffers (synchronising the stream) and a forward under stream capture that would have to grow fails with
- * RR_ERR_BAD_ARG.  The module's constructor-time analogue in the reference: none (PyTorch's caching allocator). */
+ * RR_ERR_BAD_ARG.  Graphs captured earlier stay replayable when a LATER call on the same handle (a larger rr_forward,
+ * rr_encode_image, the fusion bias) outgrows a buffer: once rr_reserve has been called or a capture has been seen on the
+ * handle, an outgrown block is retired until rr_destroy instead of freed, and the attention redo-flag buffers are never
+ * freed; such a replay computes in the old blocks it was captured with (and overlaps nothing the handle still uses).  What
+ * a replay does NOT survive: rr_destroy of the handle.  The module's constructor-time analogue in the reference: none
+ * (PyTorch's caching allocator). */
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream);
 
 /* rr_forward: one pass of the hot path over N = Bq*K (query,candidate) pairs.
@@ -344,6 +349,12 @@ int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* b
 int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in, const uint16_t* lo_in,
                            const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
                            uint16_t* x16_out, uint16_t* lo_out, float* stats_out, float* part_scratch, void* hip_stream);
+/* Test support: the fp32 residual rows the split-stream epilogue forms from a (hi, lo) pair — hi + lo, LayerNorm-recomputed when
+ * `stats` (mean, rstd per row) / gamma / beta are given — with the epilogue's own expression, so that rr_op_gemm_resid_lnprep fed
+ * these rows is a bit-exact expectation for rr_op_gemm_resid_split (tests/test_gpu_ops.py).  hi in the operand type of
+ * rr_set_op_dtype, lo fp16; cols even. */
+int rr_op_split_residual_value(const uint16_t* hi, const uint16_t* lo, const float* stats, const float* gamma, const float* beta,
+                               int rows, int cols, float* out, void* hip_stream);
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream);
 /* LayerNorm whose output is an fp8 GEMM operand: out8[row] = e4m3(LN(x[row]) / row_scale[row]), row_scale = row amax / 448,
@@ -353,7 +364,7 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
                        float* row_scale, float* stats, void* hip_stream);
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host);
 int rr_set_gemm_variant(int variant);
-int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "resid_split" (default 1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo instead of fp32), "resid_touch" (default 1), "attn_pipe" (default 0: software-pipelined tile of the 64-row attention form; measured neutral), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64, 3 = default: 2 where 256-row workgroups pad no more rows than 128-row ones, else 1; any other value restores the default) */
+int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "resid_split" (default 1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo instead of fp32), "resid_touch" (default 0: L2 touch of the next residual pass; the rows themselves are requested a pass ahead), "gemm_desync" (default 0: diagnostic start skew of the XCDs, percent of a tile period), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64, 3 = default: 2 where 256-row workgroups pad no more rows than 128-row ones, else 1; any other value restores the default) */
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */

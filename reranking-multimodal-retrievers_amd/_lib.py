@@ -100,6 +100,7 @@ _SIGS = {
     "rr_op_gemm_resid_lnprep": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P]),
     "rr_op_gemm_resid_split": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P]),
     "rr_op_gemm_lnfold": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rr_op_split_residual_value": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "rr_set_gemm_stamps": (C.c_int, [_P]),
     "rr_set_gemm_stagger": (C.c_int, [C.c_int]),
     "rr_op_layernorm": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P]),

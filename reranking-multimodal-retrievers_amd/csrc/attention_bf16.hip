@@ -104,18 +104,25 @@ __device__ __forceinline__ void load_bias_chunk(float* const b_all, int* const f
 
 // ---- output rows through a wave-private LDS slice.  The accumulators hold O^T (lane = query row, registers = head
 // dimensions), so storing them directly is 16 instructions of 8 bytes per lane that each touch 64 different rows.  Staged
-// as rows [query][64 d] (144-byte pitch) in the K/V buffers, which are free after the last tile's barrier, a wave writes
-// its rows as 16 bytes per lane, 8 lanes per 128-byte row, 8 rows per instruction (a quarter of the store instructions,
-// whole lines).  Same-wave LDS accesses execute in issue order: no barrier between the two halves.
-constexpr int O_PITCH = 144;
+// as rows [query][64 d] in the K/V buffers, which are free after the last tile's barrier, a wave writes its rows as 16
+// bytes per lane, 8 lanes per 128-byte row, 8 rows per instruction (a quarter of the store instructions, whole lines).
+// Same-wave LDS accesses execute in issue order: no barrier between the two halves.
+// Image: 128-byte rows, 16-byte chunk c of row r at chunk slot c ^ (r & 7), and in rows with bit 3 set the two 8-byte
+// halves of every chunk swapped.  Conflict-free both ways: a ds_write_b64 lane group is 16 rows of one chunk column and
+// one half — the XOR spreads rows r..r+7 over the eight chunk slots, the half swap keeps rows r and r + 8 on different
+// banks — and a ds_read_b128 lane group (four runs of four lanes in four different rows) meets four different 64-byte
+// quarters of the 256-byte bank row.  (The first version, a plain 144-byte pitch, was 2-way on the writes and on the
+// reads: SQ_LDS_BANK_CONFLICT 12.5 % of this kernel's LDS cycles in profiles/r02_z_sq_counters.json.)
+constexpr int O_PITCH = 128;
 static_assert(4 * 64 * O_PITCH <= ATTN_LDS_BYTES, "four waves x 64 output rows must fit the workgroup's LDS");
 template <int DT>
 __device__ __forceinline__ void stage_o_rows(char* slice, int row, int h, const f32x16& o0, const f32x16& o1, float inv) {
-  char* rp = slice + row * O_PITCH + 8 * h;
+  char* rp = slice + row * O_PITCH + ((8 * h) ^ (row & 8));
+  const int x = row & 7;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    *(uint2*)(rp + 16 * g) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-    *(uint2*)(rp + 64 + 16 * g) = make_uint2(pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+    *(uint2*)(rp + ((g ^ x) << 4)) = make_uint2(pack2<DT>(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2<DT>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+    *(uint2*)(rp + (((4 + g) ^ x) << 4)) = make_uint2(pack2<DT>(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2<DT>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
   }
 }
 template <int ROWS>
@@ -124,7 +131,8 @@ __device__ __forceinline__ void store_o_rows(const char* slice, int lane, bf16_t
 #pragma unroll
   for (int u = 0; u < ROWS / 8; ++u) {
     const int i = lane + 64 * u, row = i >> 3, c = i & 7;
-    const uint4 v = *(const uint4*)(slice + row * O_PITCH + c * 16);
+    uint4 v = *(const uint4*)(slice + row * O_PITCH + ((c ^ (row & 7)) << 4));
+    if (u & 1) v = make_uint4(v.z, v.w, v.x, v.y);            // row = lane/8 + 8u: bit 3 of the row is bit 0 of u
     if (row < rows_valid) *(uint4*)(out_rows + (size_t)row * out_stride + c * 8) = v;
   }
 }
@@ -525,122 +533,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       kf[2 * i + 1] = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!need_ref && (a.tuning & 2)) {
-      // ---- software-pipelined tile (every tile but the one that establishes the reference; rr_set_tuning "attn_pipe").
-      // The two 32-row chains of the wave are staggered: chain 1's QK^T MFMAs are issued with chain 0's exponentials,
-      // row sums and packs between them, chain 0's P.V MFMAs with the second half of chain 1's — the matrix pipe and the
-      // VALU of the SAME wave overlap instead of waiting for a co-resident wave to be in the other phase.  One basic
-      // block (no priority flips, no branches), the interleave pinned with sched_group_barrier.
-      typedef __attribute__((ext_vector_type(2))) float f32x2p;
-      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4p;
-      f32x16 s00, s01, s10, s11;      // chain 0 / 1, key half 0 / 1
-      if (masked) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b0 = *(const float4*)(bt_ + 8 * g + 4 * h);
-          const float4 b1 = *(const float4*)(bt_ + 32 + 8 * g + 4 * h);
-          s00[4 * g + 0] = b0.x; s00[4 * g + 1] = b0.y; s00[4 * g + 2] = b0.z; s00[4 * g + 3] = b0.w;
-          s01[4 * g + 0] = b1.x; s01[4 * g + 1] = b1.y; s01[4 * g + 2] = b1.z; s01[4 * g + 3] = b1.w;
-        }
-        s10 = s00; s11 = s01;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s00[r] = 0.f; s01[r] = 0.f; s10[r] = 0.f; s11[r] = 0.f; }
-      }
-      // chain 0: QK^T (+ reference)
-      s00 = mfma32<DT>(kone, qc[0], s00);
-      s01 = mfma32<DT>(kone, qc[0], s01);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s00 = mfma32<DT>(kf[2 * i], qf[0][i], s00);
-        s01 = mfma32<DT>(kf[2 * i + 1], qf[0][i], s01);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // chain 1: QK^T  ||  chain 0: exp, row sum, pack
-      s10 = mfma32<DT>(kone, qc[1], s10);
-      s11 = mfma32<DT>(kone, qc[1], s11);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s10 = mfma32<DT>(kf[2 * i], qf[1][i], s10);
-        s11 = mfma32<DT>(kf[2 * i + 1], qf[1][i], s11);
-      }
-      bf16x8 p0[4], p1[4];
-      {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s00[r] = __builtin_amdgcn_exp2f(s00[r]); s01[r] = __builtin_amdgcn_exp2f(s01[r]); }
-        f32x2p acc2 = {0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) { acc2 += f32x2p{s00[r], s00[r + 1]}; acc2 += f32x2p{s01[r], s01[r + 1]}; }
-        l_run[0] += acc2[0] + acc2[1];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          u32x4p w0, w1;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            w0[j] = pack2<DT>(s00[8 * st + 2 * j], s00[8 * st + 2 * j + 1]);
-            w1[j] = pack2<DT>(s01[8 * st + 2 * j], s01[8 * st + 2 * j + 1]);
-          }
-          p0[st] = __builtin_bit_cast(bf16x8, w0);          // ks = 2 kb + st: key half 0
-          p0[2 + st] = __builtin_bit_cast(bf16x8, w1);      //                 key half 1
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);    // 7 VALU (of ~68: 32 exp, 16 packed adds, 16 packs, sums)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // V fragments (the K fragments' registers are free now); the first half of chain 1's exponentials covers their latency
-      bf16x8 vf[8];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int key0 = (ks >> 1) * 32 + 16 * (ks & 1) + 4 * h;
-        const int cg = 2 * ((lane >> 4) & 1);
-        vf[2 * ks] = tr_pair(vt_, key0, 0 + cg, lane);
-        vf[2 * ks + 1] = tr_pair(vt_, key0, 4 + cg, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s10[r] = __builtin_amdgcn_exp2f(s10[r]);
-      __builtin_amdgcn_sched_barrier(0);
-      // chain 0: P.V  ||  chain 1: second half of the exponentials, row sum, pack
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        o[0][0] = mfma32<DT>(vf[2 * ks], p0[ks], o[0][0]);
-        o[0][1] = mfma32<DT>(vf[2 * ks + 1], p0[ks], o[0][1]);
-      }
-      {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s11[r] = __builtin_amdgcn_exp2f(s11[r]);
-        f32x2p acc2 = {0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) { acc2 += f32x2p{s10[r], s10[r + 1]}; acc2 += f32x2p{s11[r], s11[r + 1]}; }
-        l_run[1] += acc2[0] + acc2[1];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          u32x4p w0, w1;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            w0[j] = pack2<DT>(s10[8 * st + 2 * j], s10[8 * st + 2 * j + 1]);
-            w1[j] = pack2<DT>(s11[8 * st + 2 * j], s11[8 * st + 2 * j + 1]);
-          }
-          p1[st] = __builtin_bit_cast(bf16x8, w0);
-          p1[2 + st] = __builtin_bit_cast(bf16x8, w1);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // chain 1: P.V
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        o[1][0] = mfma32<DT>(vf[2 * ks], p1[ks], o[1][0]);
-        o[1][1] = mfma32<DT>(vf[2 * ks + 1], p1[ks], o[1][1]);
-      }
-    } else {
+    {
     f32x16 s[2][2];     // [sub-block][key half]
     auto qk = [&]() __attribute__((always_inline)) {
       if (prio) __builtin_amdgcn_s_setprio(2);
@@ -823,12 +716,10 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
 
 static unsigned long long* g_attn_stamps = nullptr;
 // kernel argument `tuning`: bit 0 = rr_set_tuning("attn_prio"): MFMA sections at wave priority 2, softmax at 0 (+4 % attention);
-// bit 1 = rr_set_tuning("attn_pipe"): the 64-row form's software-pipelined tile.
 // rr_set_tuning("attn_fixed_ref"): fixed-reference schedule (two launches) for grids of at least ATTN_FIXED_MIN_BLOCKS.
 constexpr int ATTN_FIXED_DEFAULT = 3;   // 0 online only, 1 fixed reference (32 rows per wave), 2 fixed reference (64 rows per wave),
                                         // 3 = 2 where 256-row workgroups pad no more query rows than 128-row ones do, else 1
-static int g_attn_prio_host = 1, g_attn_fixed_host = ATTN_FIXED_DEFAULT, g_attn_pipe_host = 0;   // attn_pipe: measured neutral, off
-extern "C" int rr_set_attn_pipe(int on) { g_attn_pipe_host = on != 0; return 0; }
+static int g_attn_prio_host = 1, g_attn_fixed_host = ATTN_FIXED_DEFAULT;
 constexpr long ATTN_FIXED_MIN_BLOCKS = 1024;   // below this the launch, not the softmax, is what costs
 extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; }
 extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 3) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
@@ -851,14 +742,12 @@ hipError_t attn_flags(long nblk, hipStream_t st, int** out) {
   std::lock_guard<std::mutex> lock(g_flags_mu);
   FlagBuf& f = g_flags[std::make_pair(dev, st)];
   if (f.cap < nblk) {
-    // growth synchronises and frees: not while the stream is being captured (rr_reserve sizes the buffer beforehand)
+    // growth allocates: not while the stream is being captured (rr_reserve sizes the buffer beforehand)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipErrorStreamCaptureUnsupported;
-    if (f.p) {
-      if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-      (void)hipFree(f.p);
-      f.p = nullptr; f.cap = 0;
-    }
+    // an outgrown flag buffer is NOT freed (4 bytes per workgroup; a graph captured earlier on this stream may still hold its
+    // address): it stays allocated for the life of the process
+    f.p = nullptr; f.cap = 0;
     const long cap = nblk + nblk / 2;
     if ((e = hipMalloc((void**)&f.p, (size_t)cap * sizeof(int))) != hipSuccess) { f.p = nullptr; return e; }
     f.cap = cap;
@@ -890,7 +779,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
   const dim3 grid((unsigned)nblk), block(256);
   AttnArgs a{q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups,
-             dense_bias, dense_ld, nullptr, g_attn_prio_host | (g_attn_pipe_host << 1), nullptr, (int)nblk};
+             dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk};
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
   if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {

@@ -492,6 +492,37 @@ hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const floa
   return hipGetLastError();
 }
 
+// The residual VALUE the split-stream epilogue of gemm_kernel_hp forms from a (hi, lo) row pair: x = hi + lo, then — with
+// statistics — (x - mean) * rstd * gamma + beta, the very expression (and operation order) of that epilogue, as fp32 rows.
+// Test infrastructure for tests/test_gpu_ops.py: fed to the fp32-stream epilogue it gives a bit-exact expectation for the
+// production split epilogues (x16 / lo_out), which no other kernel implements.
+__global__ void split_residual_value_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+                                            const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, size_t rows, int cols, int dt, float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= rows * (size_t)cols) return;
+  const size_t r = i / cols;
+  const int c = (int)(i - r * cols);
+  const uint32_t hw = *(const uint32_t*)(hi + i), lw = *(const uint32_t*)(lo + i);
+  const float2 h = dt ? unpack2<1>(hw) : unpack2<0>(hw), l = unpack2<1>(lw);
+  float x0 = h.x + l.x, x1 = h.y + l.y;
+  if (stats) {
+    const float2 st = stats[r];
+    x0 = (x0 - st.x) * st.y * gamma[c] + beta[c];
+    x1 = (x1 - st.x) * st.y * gamma[c + 1] + beta[c + 1];
+  }
+  out[i] = x0;
+  out[i + 1] = x1;
+}
+hipError_t rr_launch_split_residual_value(const bf16_t* hi, const bf16_t* lo, const float* stats, const float* gamma, const float* beta,
+                                          int rows, int cols, int dt, float* out, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || (cols & 1) || !hi || !lo || !out || (stats && (!gamma || !beta))) return hipErrorInvalidValue;
+  const size_t pairs = (size_t)rows * cols / 2;
+  hipLaunchKernelGGL(split_residual_value_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, hi, lo, (const float2*)stats,
+                     gamma, beta, (size_t)rows, cols, dt, out);
+  return hipGetLastError();
+}
+
 hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || nparts != (cols + 127) / 128 || !part || !stats) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float2*)part, nparts, cols, eps,

@@ -28,6 +28,8 @@ hipError_t rr_launch_joint_masks(const int64_t*, const int64_t*, int, int, int, 
                                  hipStream_t);
 hipError_t rr_launch_interaction_bias(const float*, const float*, int, int, int, int, int, float*, float*, float*,
                                       hipStream_t);
+hipError_t rr_launch_split_residual_value(const bf16_t* hi, const bf16_t* lo, const float* stats, const float* gamma, const float* beta,
+                                          int rows, int cols, int dt, float* out, hipStream_t st);
 hipError_t rr_launch_layernorm_stats(const float*, const float*, const float*, float, int, int, float*, bf16_t*, float*,
                                      int, hipStream_t);
 hipError_t rr_launch_key_bias(const int64_t*, const int64_t*, int, int, int, float*, float*, hipStream_t);
@@ -176,6 +178,8 @@ struct rr_model {
   // workspace (grow-only)
   char* ws = nullptr;
   size_t ws_cap = 0;
+  bool pinned_blocks = false;          // rr_reserve was called or a stream capture was seen: outgrown blocks are retired, not freed
+  std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
 
   // last-forward taps
   bool debug = false;
@@ -632,22 +636,39 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   return (b.off + 255) & ~(size_t)255;
 }
 
-// Growth outside rr_reserve synchronises the stream and frees the old block: legal on a plain stream, not while the
-// stream is being captured into a graph (and it would invalidate pointers baked into earlier captures) -> refused there.
+// Growth outside rr_reserve synchronises the stream and replaces the old block: legal on a plain stream, not while the
+// stream is being captured into a graph -> refused there.  A graph captured EARLIER holds the old block's address in its
+// kernel nodes: once rr_reserve has been called or a capture has been seen on this handle (pinned_blocks), an outgrown
+// block is not freed but retired until rr_destroy, so that replaying such a graph after a later, larger forward stays
+// valid (it computes in the old block).
 int capture_guard(rr_model* m, hipStream_t st, const char* what) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    m->pinned_blocks = true;
     return fail(m, RR_ERR_BAD_ARG, "%s would have to grow during stream capture; call rr_reserve for the largest shape "
                                    "before capturing", what);
+  }
+  return RR_OK;
+}
+// every forward notes a capture in progress, also when nothing has to grow
+void note_capture(rr_model* m, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (!m->pinned_blocks && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) m->pinned_blocks = true;
+}
+int release_block(rr_model* m, void* p, hipStream_t st) {
+  if (!p) return RR_OK;
+  RR_HIP(m, hipStreamSynchronize(st));
+  if (m->pinned_blocks) m->retired.push_back(p);
+  else RR_HIP(m, hipFree(p));
   return RR_OK;
 }
 
 int ensure_ws(rr_model* m, size_t bytes, hipStream_t st) {
+  note_capture(m, st);
   if (bytes <= m->ws_cap) return RR_OK;
   RR_TRY(capture_guard(m, st, "the workspace"));
   if (m->ws) {
-    RR_HIP(m, hipStreamSynchronize(st));
-    RR_HIP(m, hipFree(m->ws));
+    RR_TRY(release_block(m, m->ws, st));
     m->ws = nullptr;
     m->ws_cap = 0;
   }
@@ -669,7 +690,6 @@ extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
-extern "C" int rr_set_attn_pipe(int on);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
 
 // Where a layer's residual comes from: either materialised fp32 rows (after an embedding LayerNorm), or the previous
@@ -834,7 +854,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
 int ensure_adj(rr_model* m, size_t bytes, hipStream_t st) {
   if (bytes <= m->adj_cap) return RR_OK;
   RR_TRY(capture_guard(m, st, "the attention-fusion bias buffer"));
-  if (m->adj) { RR_HIP(m, hipStreamSynchronize(st)); RR_HIP(m, hipFree(m->adj)); m->adj = nullptr; m->adj_cap = 0; }
+  if (m->adj) { RR_TRY(release_block(m, m->adj, st)); m->adj = nullptr; m->adj_cap = 0; }
   RR_HIP(m, hipMalloc((void**)&m->adj, bytes));
   m->adj_cap = bytes;
   return RR_OK;
@@ -1004,6 +1024,7 @@ static int rr_destroy_impl(rr_handle h) {
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
   for (void* p : h->dev_allocs) (void)hipFree(p);
+  for (void* p : h->retired) (void)hipFree(p);
   if (h->ws) (void)hipFree(h->ws);
   if (h->tap_text) (void)hipFree(h->tap_text);
   if (h->adj) (void)hipFree(h->adj);
@@ -1155,6 +1176,7 @@ static int rr_reserve_impl(rr_handle h, int n_pairs, int n_queries, int len_a, i
     T = len_a + len_b;
   }
   RR_HIP(m, rr_attention_reserve(n_pairs, c.ce_heads, T, st));
+  m->pinned_blocks = true;               // from here on outgrown blocks are retired, not freed (a graph may hold their addresses)
   RR_TRY(ensure_ws(m, need, st));
   if (with_fusion) RR_TRY(ensure_adj(m, (size_t)n_pairs * T * ((T + 63) / 64 * 64) * sizeof(float), st));
   return RR_OK;
@@ -1624,7 +1646,6 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
-  if (!strcmp(key, "attn_pipe")) return rr_set_attn_pipe(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);
   return RR_ERR_BAD_ARG;
@@ -1752,6 +1773,12 @@ static int rr_op_gemm_lnfold_impl(const uint16_t* A_raw, const uint16_t* W_folde
                                      epi_map[epilogue], g_op_dt, (hipStream_t)hip_stream);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
+static int rr_op_split_residual_value_impl(const uint16_t* hi, const uint16_t* lo, const float* stats, const float* gamma,
+                                           const float* beta, int rows, int cols, float* out, void* hip_stream) {
+  if (!hi || !lo || !out) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_split_residual_value(hi, lo, stats, gamma, beta, rows, cols, g_op_dt, out, (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
 static int rr_op_layernorm_stats_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                           float* out_f32, uint16_t* out_bf16, float* stats, void* hip_stream) {
   if (!x || !gamma || !beta || !out_bf16 || !stats) return RR_ERR_BAD_ARG;
@@ -1838,6 +1865,10 @@ int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bi
                            const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
                            uint16_t* x16_out, uint16_t* lo_out, float* stats_out, float* part_scratch, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_gemm_resid_split_impl(A, W, bias, hi_in, lo_in, ln_stats, ln_gamma, ln_beta, M, N, Kd, eps, x16_out, lo_out, stats_out, part_scratch, hip_stream); });
+}
+int rr_op_split_residual_value(const uint16_t* hi, const uint16_t* lo, const float* stats, const float* gamma, const float* beta,
+                               int rows, int cols, float* out, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_split_residual_value_impl(hi, lo, stats, gamma, beta, rows, cols, out, hip_stream); });
 }
 int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const float* dvec, const float* csum, const float* stats,
                       int M, int N, int Kd, int epilogue, void* out, void* hip_stream) {

@@ -32,6 +32,17 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert set(names) == set(_lib.EXPORTED), "ctypes table and header disagree"
 
 
+def test_gemm_objects_hold_no_packed_f32(lib):
+    """The build refuses device code with compiler-formed v_pk_{add,mul,fma}_f32 in the GEMM / elementwise objects (gfx950
+    stale-lane hazard behind a vmcnt wait, DESIGN.md "Numerics"); here the check runs on the objects the library was linked from."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rr_build", os.path.join(ROOT, "reranking-multimodal-retrievers_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for o in b.NO_PACKED_F32:
+        b.check_no_packed_f32(os.path.join(b.HERE, "build", o))
+
+
 def test_version_and_status_strings(lib):
     assert b"gfx950" in lib.rr_version()
     assert lib.rr_status_string(0) == b"ok"

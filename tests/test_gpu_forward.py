@@ -447,6 +447,49 @@ def test_reserved_forward_is_capturable_into_a_graph():
     assert torch.equal(out["order"], r["order"])
 
 
+def test_graph_replay_survives_a_later_larger_forward():
+    """a graph captured after rr_reserve holds the workspace / redo-flag addresses in its kernel nodes.  A later,
+    larger forward on the same handle and stream must not free them: outgrown blocks are retired until rr_destroy.  The
+    shape takes the fixed-reference attention schedule (640 pairs x 2 heads = 1 280 workgroups >= 1 024), so the redo-flag
+    buffer is part of the capture; the graph is replayed after the handle has grown to twice the batch."""
+    g = load_golden("tiny_mm")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=True)
+    eng = _engine(cfg, True, w)
+    S = g["S"]
+
+    def batch(Bq, K, seed):
+        ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=seed)
+        cls, pat = O.make_image_feats(cfg, Bq, seed=seed)
+        return (ids.cuda(), am.cuda(), tt.cuda(), Bq, K, cls.cuda(), pat.cuda(), None)
+    small, big = batch(8, 80, 5), batch(16, 80, 6)
+    eager = eng.forward_ids(*small, want_order=True)
+    torch.cuda.synchronize()
+    ref_logits, ref_order = eager["logits"].clone(), eager["order"].clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eng.reserve(640, 8, S)
+        eng.forward_ids(*small, want_order=True)               # warm-up on the capture stream
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            out = eng.forward_ids(*small, want_order=True)
+        out["logits"].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out["logits"], ref_logits) and torch.equal(out["order"], ref_order)
+        r_big = eng.forward_ids(*big, want_order=True)          # outgrows the workspace and the flag buffer of this stream
+        torch.cuda.synchronize()
+        assert torch.isfinite(r_big["logits"]).all()
+        out["logits"].zero_()
+        graph.replay()                                          # still computes in the blocks it was captured with
+        torch.cuda.synchronize()
+        assert torch.equal(out["logits"], ref_logits) and torch.equal(out["order"], ref_order)
+        again = eng.forward_ids(*small, want_order=True)        # and the handle itself is intact
+        torch.cuda.synchronize()
+        assert torch.equal(again["logits"], ref_logits)
+
+
 def test_lightning_checkpoint_keys_load_through_the_prefix():
     """Reranker_base_executor.py:351-381 loads `checkpoint['state_dict']` with strict=False: keys carry the executor's
     `reranker.` prefix, tensors may be bf16/fp16 (mixed-precision checkpoints), and unrelated entries (optimizer/metric
