@@ -83,3 +83,33 @@ def load_fullsize(name):
                 q[k] = z[f"q{qi}.{k}"]
         qs.append(q)
     return cfg, w, vision, qs
+
+
+def margin_stats(got, ref):
+    """max |d|, max |d - mean d| (what a ranking sees), Spearman rank correlation and top-5 overlap of two logit vectors."""
+    got, ref = got.flatten().double(), ref.flatten().double()
+    d = got - ref
+    rho = torch.corrcoef(torch.stack([ref.argsort().argsort().double(), got.argsort().argsort().double()]))[0, 1].item() \
+        if got.numel() > 2 else 1.0
+    k = min(5, got.numel())
+    top5 = len(set(ref.argsort(descending=True)[:k].tolist()) & set(got.argsort(descending=True)[:k].tolist()))
+    return dict(max_abs=float(d.abs().max()), centred=float((d - d.mean()).abs().max()), rho=float(rho), top5=f"{top5}/{k}",
+                n=int(got.numel()), ref_std=float(ref.std()) if got.numel() > 1 else 0.0)
+
+
+def record_margin(key, **metrics):
+    """Append measured parity margins to a JSON the builder commits as profiles/rNN_parity_margins.json (`pytest -q` prints
+    nothing): $RR_MARGINS_JSON or gpurun_out/parity_margins.json under the repo root.  Never fails a test."""
+    import json
+    path = os.environ.get("RR_MARGINS_JSON", os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[key] = metrics
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except Exception:      # noqa: BLE001 — bookkeeping only
+        pass

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import O, arch_from_cfg, autocast_drift, bf16_gate, golden_inputs, load_golden
+from helpers import O, arch_from_cfg, autocast_drift, bf16_gate, golden_inputs, load_golden, margin_stats, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,7 @@ def test_forward_matches_golden_and_oracle(name):
     assert torch.isfinite(logits).all()
     gold = torch.from_numpy(g["logits"]).reshape(-1)
     d32 = (logits - gold).abs().max().item()
+    record_margin(f"{name}/bf16", gate=bf16_gate(name), **margin_stats(logits, gold))
     ids, am, tt, img = golden_inputs(g)
     torch.set_num_threads(8)
     with torch.no_grad(), O.device_rounding() as mm:
@@ -103,6 +104,7 @@ def test_fp16_operand_mode_is_within_1e3_of_fp32_goldens(name):
         emu = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, img[0], img[1], g["labels_list"], mm=mm)
     demu = (logits - emu.logits.reshape(-1)).abs().max().item()
     print(f"[{name}/fp16] |dlogit| vs fp32 golden {d32:.2e}, vs same-rounding oracle {demu:.2e}")
+    record_margin(f"{name}/fp16", gate=TOL_FP16, vs_same_rounding_oracle=demu, **margin_stats(logits, gold))
     assert d32 <= TOL_FP16
     assert demu <= TOL_FP16
     assert abs(r["loss"].item() - float(g["loss"])) < 1e-3
@@ -379,14 +381,16 @@ def test_bert_large_shape_text_only():
     ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=21, regime="realistic")
     with torch.no_grad():
         ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K)
-    # measured: fp16 9.9e-4 (|logit| up to 1.23, i.e. 8e-4 relative after 25 layers), bf16 2.8e-3
-    for dtype, tol in (("fp16", 1.5e-3), ("bf16", 8e-3)):
+    # measured (profiles/r03_parity_margins.json): fp16 9.9e-4 (|logit| up to 1.23, i.e. 8e-4 relative after 25 layers — the one
+    # case a hair under 1e-3, hence a gate of 1.3 x measured), bf16 5.1e-3 (gate 1.3 x)
+    for dtype, tol in (("fp16", 1.3e-3), ("bf16", 6.7e-3)):
         eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, False, dtype))
         eng.load_state_dict(w)
         r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K, want_order=True)
         torch.cuda.synchronize()
         d = (r["logits"].cpu() - ref.logits.reshape(-1)).abs().max().item()
         print(f"[bert-large shape/{dtype}] |dlogit| vs fp32 oracle {d:.2e} (|logit| max {ref.logits.abs().max().item():.2f})")
+        record_margin(f"bert_large_shape_K4_S128/{dtype}", gate=tol, **margin_stats(r["logits"].cpu(), ref.logits.reshape(-1)))
         assert torch.isfinite(r["logits"]).all() and d <= tol
         assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in r["logits"].view(Bq, K).cpu().tolist()]
         del eng

@@ -204,6 +204,10 @@ def test_fp8_forward_small_model_against_the_oracle_emulation(dt):
     assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
 
 
+# gates of the e4m3 drift on c5_full: <= 2 x the figures measured at HEAD (profiles/r03_parity_margins.json), VERDICT r2 item 2b
+FP8_GATE_ABS, FP8_GATE_CENTRED = 0.09, 0.078            # measured 4.6e-2 / 3.9e-2 (rank correlation 0.970, top-5 overlap 3/5)
+
+
 def test_fp8_forward_bert_large_against_the_c5_golden():
     """BASELINE configs[4]: bert-large, K = 200, S = 512, e4m3 QKV / FFN-up GEMMs.  north_star's 1e-3 is a 16-bit
     figure; for e4m3 the drift from the committed fp32 stock-HF logits is REPORTED and bounded: absolute, and centred per
@@ -226,6 +230,9 @@ def test_fp8_forward_bert_large_against_the_c5_golden():
     top5 = len(set(ref.argsort(descending=True)[:5].tolist()) & set(got.argsort(descending=True)[:5].tolist()))
     print(f"[c5_full/fp8+fp16] K={K}: |dlogit| vs fp32 max {d.abs().max():.3e}, centred {dc.abs().max():.3e}; logit std over the list "
           f"{ref.std():.3f}; rank correlation {rho:.4f}; top-5 overlap {top5}/5; reference bf16-autocast drift {(ac - ref).abs().max():.3e}")
+    from helpers import margin_stats, record_margin
+    record_margin("c5_full/fp8+fp16", gate_abs=FP8_GATE_ABS, gate_centred=FP8_GATE_CENTRED, reference_bf16_autocast_drift=float((ac - ref).abs().max()),
+                  **margin_stats(got, ref))
     assert torch.isfinite(got).all()
-    assert d.abs().max().item() <= 0.25 and dc.abs().max().item() <= 0.08
+    assert d.abs().max().item() <= FP8_GATE_ABS and dc.abs().max().item() <= FP8_GATE_CENTRED
     assert rho >= 0.9

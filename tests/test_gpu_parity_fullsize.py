@@ -3,14 +3,15 @@ run_fullsize_case): c3_full (K = 100, S = 512, 81 vision tokens), c5_full (bert-
 (monoPreFLMR-L geometry: 1024-d ViT-L/14 features, 288 vision tokens, T = 800, position table 900) and c3_sep, the
 Recall@5 fixture whose fp32 logits leave a designed gap between rank 5 and rank 6.
 
-Gates: compute_dtype = fp16 (the headline mode): |logit - fp32| <= 1e-3 (north_star) — 2e-3 on the 25-layer bert-large
-stack, where the reference's own bf16-mixed forward is 1e-2 from fp32; compute_dtype = bf16: helpers.bf16_gate (the
-reference's own autocast drift on the same inputs)."""
+Gates: compute_dtype = fp16 (the headline mode): |logit - fp32| <= 1e-3 (north_star) on every golden, the 25-layer bert-large
+stack included (measured 8.6e-4 there; the reference's own bf16-mixed forward is 1e-2 from fp32); compute_dtype = bf16:
+helpers.bf16_gate (the reference's own autocast drift on the same inputs).  Every measured margin is written to
+gpurun_out/parity_margins.json by helpers.record_margin and committed as profiles/rNN_parity_margins.json."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import O, arch_from_cfg, load_fullsize
+from helpers import O, arch_from_cfg, load_fullsize, margin_stats, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +33,9 @@ def _logits(eng, q, sel=None, want_order=False):
     return r
 
 
-@pytest.mark.parametrize("name,tol16", [("c3_full", 1e-3), ("l_shape", 1e-3), ("c5_full", 2e-3)])
+# measured at HEAD (profiles/r03_parity_margins.json): fp16 3.2e-4 / 1.7e-4 / 8.6e-4 — north_star's 1e-3 on all three, the 25-layer
+# bert-large stack included (the round-2 gate there was 2e-3)
+@pytest.mark.parametrize("name,tol16", [("c3_full", 1e-3), ("l_shape", 1e-3), ("c5_full", 1e-3)])
 def test_full_size_logits_match_the_fp32_goldens(name, tol16):
     cfg, w, vision, qs = load_fullsize(name)
     q = qs[0]
@@ -43,6 +46,7 @@ def test_full_size_logits_match_the_fp32_goldens(name, tol16):
         d = (lg - q["fp32"]).abs().max().item()
         gate = tol16 if dt == "fp16" else max(1e-3, 1.5 * ac)
         print(f"[{name}/{dt}] K={len(lg)} |dlogit| vs fp32 {d:.2e} (gate {gate:.1e}); reference's bf16-autocast drift {ac:.2e}")
+        record_margin(f"{name}/{dt}", gate=gate, reference_bf16_autocast_drift=ac, **margin_stats(lg, q["fp32"]))
         assert torch.isfinite(lg).all()
         assert d <= gate
         del eng
@@ -70,6 +74,7 @@ def test_recall_at_5_and_top5_sets_match_the_fp32_reference(dt):
         ref_order = O.rank_descending_stable(ref.tolist())
         d = (lg - ref).abs().max().item()
         print(f"[c3_sep/{dt} q{qi}] |dlogit| vs fp32 {d:.2e}, logit std {ref.std():.3f}, rank-5/6 gap {float(q['gap_5_6']):.3f}")
+        record_margin(f"c3_sep/q{qi}/{dt}", gate=0.5 * float(q["gap_5_6"]), gap_5_6=float(q["gap_5_6"]), **margin_stats(lg, ref))
         assert order == O.rank_descending_stable(lg.tolist())
         assert set(order[:5]) == set(ref_order[:5])
         assert d < 0.5 * float(q["gap_5_6"])
@@ -82,3 +87,32 @@ def test_recall_at_5_and_top5_sets_match_the_fp32_reference(dt):
     want = O.recall_precision_at_k(ranked_ref, pos, [5, 10])
     assert got == want
     assert got["recall"] == [0.5, 1.0]                       # query 0 hits at rank 5, query 1 only at rank 6
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_split_residual_stream_costs_no_accuracy(dt):
+    """VERDICT r2 item 2c.  The split residual stream (hi = the 16-bit operand rows, lo = fp16 remainder) carries 22 (fp16
+    operands) / 19 (bf16) bits of every pre-LayerNorm row instead of 24.  Its logits differ from the fp32-stream build's by
+    RE-DECIDED operand roundings downstream (a 2^-19 relative perturbation of a row flips the 8-bit rounding of ~1 element
+    in 2 000, each flip moves an operand by 2^-8): in bf16 mode that is the same chaotic ~2e-3 any two correct bf16
+    forwards differ by (DESIGN.md "Numerics"), not lost accuracy.  What is gated is therefore the distance to the fp32
+    GOLDEN: with the split stream it must not be worse than with fp32 rows beyond 15 % (+ 1e-4), and in fp16 mode the two
+    builds must agree within 5e-4.  Both distances and the build-to-build difference are recorded."""
+    from rmr_amd import _lib
+    lib = _lib.load()
+    cfg, w, vision, qs = load_fullsize("c3_full")
+    q = qs[0]
+    eng = _engine(cfg, vision, w, dt)
+    try:
+        on = _logits(eng, q)["logits"].cpu()
+        assert lib.rr_set_tuning(b"resid_split", 0) == 0
+        off = _logits(eng, q)["logits"].cpu()
+    finally:
+        lib.rr_set_tuning(b"resid_split", 1)
+    d_on, d_off = (on - q["fp32"]).abs().max().item(), (off - q["fp32"]).abs().max().item()
+    between = (on - off).abs().max().item()
+    print(f"[c3_full/{dt}] vs fp32 golden: split stream {d_on:.2e}, fp32 stream {d_off:.2e}; split vs fp32 stream {between:.2e}")
+    record_margin(f"c3_full/{dt}/split_vs_fp32_stream", split_vs_golden=d_on, fp32_stream_vs_golden=d_off, split_vs_fp32_stream=between)
+    assert d_on <= 1.15 * d_off + 1e-4
+    if dt == "fp16":
+        assert between <= 5e-4
