@@ -14,15 +14,23 @@ from typing import Dict, List
 import torch
 
 
-def prepare_full_context_inputs(query_text_sequences: List[str], context_text_sequences: List[str], tokenizer,
-                                max_query_length: int, max_context_length: int, max_decoder_source_length: int,
-                                docs_per_query: int) -> Dict[str, torch.Tensor]:
+def truncate_and_pair(query_text_sequences: List[str], context_text_sequences: List[str], tokenizer, max_query_length: int,
+                      max_context_length: int, docs_per_query: int) -> List[tuple]:
+    """utils.py:131-153: queries / contexts cut to their token budgets by an encode -> decode round trip (no special tokens),
+    then paired query-major.  Pinned to the reference's own loop executed from source (tests/golden/reference_fn.npz `pfc.*`)."""
     def clip(text: str, n: int) -> str:
         return tokenizer.decode(tokenizer.encode(text, add_special_tokens=False, max_length=n, truncation=True))
 
     queries = [clip(t, max_query_length) for t in query_text_sequences]
     contexts = [clip(t, max_context_length) for t in context_text_sequences]
-    pairs = [(q, contexts[i * docs_per_query + j]) for i, q in enumerate(queries) for j in range(docs_per_query)]
+    return [(q, contexts[i * docs_per_query + j]) for i, q in enumerate(queries) for j in range(docs_per_query)]
+
+
+def prepare_full_context_inputs(query_text_sequences: List[str], context_text_sequences: List[str], tokenizer,
+                                max_query_length: int, max_context_length: int, max_decoder_source_length: int,
+                                docs_per_query: int) -> Dict[str, torch.Tensor]:
+    pairs = truncate_and_pair(query_text_sequences, context_text_sequences, tokenizer, max_query_length, max_context_length,
+                              docs_per_query)
     kw = dict(add_special_tokens=True, return_tensors="pt", padding="max_length", truncation=True,
               max_length=max_decoder_source_length, return_attention_mask=True, return_token_type_ids=True)
     if hasattr(tokenizer, "batch_encode_plus"):          # transformers 4.x (the reference pins 4.38.2)

@@ -19,8 +19,18 @@ What is pinned (reference file:lines -> oracle function the CPU tests compare ag
   interaction_rerank_model.py:125-145  interaction fusion bias  -> the bias of O.interaction_forward
   metrics_processors.py:828-884  Recall/Precision@K accumulation -> O.recall_precision_at_k / rmr_amd.ranking
   Reranker_base_executor.py:934-935  sorted(zip(docs, logits), reverse=True) -> O.rank_descending_stable
-  utils.py:129-167   prepare_full_context_inputs (with the installed HF BertTokenizer on a seeded vocabulary)
-                                                              -> rmr_amd.pair_inputs.prepare_full_context_inputs, rr_tok_prepare_pairs
+  utils.py:131-153   prepare_full_context_inputs, the truncate-by-round-trip + query-major pairing loop (with the installed HF
+                     BertTokenizer on a seeded vocabulary; the closing tokenizer.batch_encode_plus call, :157-165, does not
+                     exist in the installed transformers 5.x and is NOT executed) -> rmr_amd.pair_inputs.truncate_and_pair
+  rerank_model.py:345-478  RerankModel.query, every statement of the body, and
+  rerank_model.py:541-590  FullContextRerankModel.forward from the image repeat to the 2H_BCE slice, with
+  utils.py:88-108    CrossEncoder.forward — `self.*` bound to stock HF modules carrying seeded weights (BertModel for the
+                     text encoder and for the cross encoder's AttentionFusionBertModel, which is only ever called with
+                     attention_adj=None here; BertEncoder(is_decoder, add_cross_attention) for the mapping network;
+                     CLIPVisionModel for the vision tower), nn.Linear, and the reference's own FLMRMultiLayerPerceptron
+                     (modeling_flmr.py:531-546, executed from the AST).  The `return EasyDict(...)` statements are not
+                     executed; their keyword expressions are evaluated one by one
+                                                              -> O.query_stage / O.full_context_forward (taps)
 Classes that subclass HuggingFace internals (AttentionFusionBertModel, MORES_BertLayer: copies of / calls into the
 4.38.2 `BertModel.forward` / `BertAttention.forward` signatures) are attempted as well and reported; they do not run
 against the installed transformers 5.x and are NOT adapted.
@@ -83,6 +93,137 @@ def NS(**kw):
     return types.SimpleNamespace(**kw)
 
 
+def eval_expr(node, ns, filename):
+    e = ast.Expression(body=node)
+    ast.fix_missing_locations(e)
+    return eval(compile(e, filename, "eval"), ns)
+
+
+def run_body(fn: ast.FunctionDef, ns, filename, lo=None, hi=None):
+    """Execute the top-level statements of `fn` (optionally only those inside source lines [lo, hi]) except `return`
+    statements; returns the Return node met last (its value is evaluated by the caller, piece by piece)."""
+    ret = None
+    stmts = []
+    for st in fn.body:
+        if lo is not None and (st.lineno < lo or st.end_lineno > hi):
+            continue
+        if isinstance(st, ast.Return):
+            ret = st
+            continue
+        if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant) and isinstance(st.value.value, str):
+            continue                                           # docstring
+        stmts.append(st)
+    run_statements(stmts, ns, filename)
+    return ret
+
+
+def glue_fixture(rec, report, ns_utils):
+    """RerankModel.query and FullContextRerankModel.forward executed from the reference's text."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from oracle import rerank_oracle as O
+    import make_golden as MG
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    kw = dict(vocab_size=300, hidden=64, layers=2, heads=2, intermediate=128, max_pos=32, li_dim=16, ce_hidden=64, ce_layers=1,
+              ce_heads=2, ce_intermediate=128, ce_max_pos=64, vision_hidden=32, prefix_len=2, n_patches=4, map_layers=1,
+              cross_attn_len=8, vit_layers=2, vit_heads=2, vit_intermediate=64, vit_image_size=32, vit_patch_size=16)
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = "BCE"
+    w, wv = O.make_weights(cfg, seed=3, vision=True), O.make_vit_weights(cfg, seed=5)
+    hf = MG.HFAssembly(cfg, w, True)                         # stock BertModel x2 + BertEncoder with the seeded weights
+    hc = CLIPVisionConfig(hidden_size=cfg.vision_hidden, intermediate_size=cfg.vit_intermediate, num_hidden_layers=cfg.vit_layers,
+                          num_attention_heads=cfg.vit_heads, image_size=cfg.vit_image_size, patch_size=cfg.vit_patch_size,
+                          hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager")
+    clip = CLIPVisionModel(hc).eval()
+    sd = clip.state_dict()
+    pref = "vision_model." if next(iter(sd)).startswith("vision_model.") else ""
+    clip.load_state_dict({k: wv.get(O.VIT_PREFIX + "." + k[len(pref):], t) for k, t in sd.items()})
+
+    def lin(name, bias=True):
+        W = w[name + ".weight"]
+        m = nn.Linear(W.shape[1], W.shape[0], bias=bias)
+        with torch.no_grad():
+            m.weight.copy_(W)
+            if bias:
+                m.bias.copy_(w[name + ".bias"])
+        return m.eval()
+    # the reference's own MLP class, executed from modeling_flmr.py's AST
+    tree_f, _ = parse("src/models/flmr/models/flmr/modeling_flmr.py")
+    nsf = dict(torch=torch, nn=nn)
+    compile_defs([next(n for n in tree_f.body if isinstance(n, ast.ClassDef) and n.name == "FLMRMultiLayerPerceptron")], nsf,
+                 "reference:modeling_flmr.py:531-546")
+    D, PL, Vh = cfg.li_dim, cfg.prefix_len, cfg.vision_hidden
+    mlp = nsf["FLMRMultiLayerPerceptron"]((Vh, D * PL // 2, D * PL)).eval()
+    with torch.no_grad():
+        for i in (0, 2):
+            mlp.model[i].weight.copy_(w[f"context_vision_projection.model.{i}.weight"])
+            mlp.model[i].bias.copy_(w[f"context_vision_projection.model.{i}.bias"])
+
+    tree, _ = parse("src/models/rerank/rerank_model.py")
+    nsm = dict(torch=torch, F=F, logger=logging.getLogger("reference"))
+    compile_defs([find_def(tree, "query_mask", "RerankModel"), find_def(tree, "mask", "RerankModel")], nsm, "reference:rerank_model.py")
+    query_def = find_def(tree, "query", "RerankModel")
+    fwd_def = find_def(tree, "forward", "FullContextRerankModel")
+    tree_u, _ = parse("src/models/rerank/utils.py")
+    ce_fwd = find_def(tree_u, "forward", "CrossEncoder")
+
+    me = NS(device=torch.device("cpu"), dtype=torch.float32, instruction_token_id=None, mask_instruction=False,
+            context_text_encoder=hf.text, context_text_encoder_linear=lin("context_text_encoder_linear", bias=False),
+            context_vision_encoder=lambda pixel_values, output_hidden_states=True: clip(pixel_values=pixel_values, output_hidden_states=True),
+            context_vision_projection=mlp, late_interaction_embedding_size=D,
+            transformer_mapping_input_linear=lin("transformer_mapping_input_linear"),
+            transformer_mapping_cross_attention_length=cfg.cross_attn_len, transformer_mapping_network=hf.mapnet,
+            transformer_mapping_output_linear=lin("transformer_mapping_output_linear"),
+            cross_encoder_input_mapping=lin("cross_encoder_input_mapping"),
+            config=NS(loss_fn="BCE", pos_weight=None))
+    me.mask = types.MethodType(nsm["mask"], me)
+    me.query_mask = types.MethodType(nsm["query_mask"], me)
+    me.loss_fn = ns_utils["initialise_loss_fn"](me.config, torch.device("cpu"))
+
+    def query(**kwargs):                                      # every statement of RerankModel.query but its return
+        env = dict(torch=torch, self=me, invert_attention_mask=ns_utils["invert_attention_mask"], **kwargs)
+        ret = run_body(query_def, env, "reference:rerank_model.py:345-474")
+        assert isinstance(ret.value, ast.Call) and getattr(ret.value.func, "id", "") == "EasyDict"
+        return NS(**{k.arg: eval_expr(k.value, env, "reference:rerank_model.py:476-478") for k in ret.value.keywords})
+    me.query = query
+
+    def bert_model(**kwargs):                                 # AttentionFusionBertModel with attention_adj=None == stock BertModel
+        assert kwargs.pop("attention_adj") is None
+        return hf.ce(**kwargs)
+    ce_self = NS(bert_model=bert_model, classifier1=lin("reranker.classifier1"), classifier2=lin("reranker.classifier2"))
+
+    def reranker(inputs_embeds, attention_mask=None, attention_adj=None, token_type_ids=None):   # CrossEncoder.forward, utils.py:88-108
+        env = dict(self=ce_self, inputs_embeds=inputs_embeds, attention_mask=attention_mask, attention_adj=attention_adj,
+                   token_type_ids=token_type_ids)
+        ret = run_body(ce_fwd, env, "reference:utils.py:88-106")
+        return eval_expr(ret.value, env, "reference:utils.py:108")
+    me.reranker = reranker
+
+    Bq, K, S = 2, 3, 24
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=9, regime="realistic")
+    px = O.make_pixel_values(cfg, Bq, seed=2022)
+    labels = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+    env = dict(torch=torch, self=me, prepare_logits_labels=ns_utils["prepare_logits_labels"], text_only=False, batch_size=Bq,
+               expanded_batch_size=Bq * K, num_negative_examples=K - 1, query_pixel_values=px, labels=labels,
+               inputs=NS(input_ids=ids, attention_mask=am, token_type_ids=tt))
+    with torch.no_grad():
+        run_body(fwd_def, env, "reference:rerank_model.py:541-590", lo=541, hi=590)
+    qo = env["query_outputs"]
+    rec["glue.cfg_json"] = np.array(repr(kw))
+    rec["glue.weight_seed"], rec["glue.vit_weight_seed"], rec["glue.Bq"], rec["glue.K"], rec["glue.S"] = 3, 5, Bq, K, S
+    rec["glue.input_ids"], rec["glue.attention_mask"], rec["glue.token_type_ids"] = ids.numpy(), am.numpy(), tt.numpy()
+    rec["glue.pixel_values"], rec["glue.labels"] = px.numpy(), np.array(labels, dtype=np.float32)
+    rec["glue.late_interaction_output"] = qo.late_interaction_output.numpy()
+    rec["glue.pooler_output"] = qo.pooler_output.numpy()
+    rec["glue.query_mask"] = qo.query_mask.numpy()
+    rec["glue.reranker_inputs"] = env["reranker_inputs"].numpy()
+    rec["glue.reranker_attention_mask"] = env["reranker_attention_mask"].numpy()
+    rec["glue.logits"], rec["glue.loss"] = env["logits"].numpy(), np.array(env["loss"].item(), dtype=np.float32)
+    report.append("rerank_model.py:345-478 (RerankModel.query), :541-590 (FullContextRerankModel.forward) and utils.py:88-108 "
+                  "(CrossEncoder.forward) executed over stock HF modules with seeded weights")
+
+
+
 def main():
     torch.manual_seed(0)
     rng = np.random.Generator(np.random.PCG64(2022))
@@ -130,6 +271,7 @@ def main():
     report.append("utils.py: prepare_logits_labels, initialise_loss_fn, invert_attention_mask executed")
     global ns_utils_invert
     ns_utils_invert = ns["invert_attention_mask"]          # the reference's own function, for mores_model.py's import of it
+    ns_utils_all = ns                                        # prepare_logits_labels / initialise_loss_fn / invert_attention_mask
 
     # ------------------------------------------------------------------ rerank_model.py: masks
     tree, _ = parse("src/models/rerank/rerank_model.py")
@@ -256,20 +398,30 @@ def main():
             open(vp, "w", encoding="utf-8").write("\n".join(vocab) + "\n")
             tok = BertTokenizer(vp, do_lower_case=True)
         tree_u, _ = parse("src/models/rerank/utils.py")
-        nsu = dict(torch=torch)
-        compile_defs([find_def(tree_u, "prepare_full_context_inputs")], nsu, "reference:utils.py:129-167")
+        pfc = find_def(tree_u, "prepare_full_context_inputs")
         queries = ["What is the color of this bus?", "Café in Tōkyō street, London: red bus or big city buses"]
         ctxs = ["London buses are usually red.", "a big city street " * 30, "日本語 bus", "", "they have (big) buses",
                 "x" * 150 + " is not a word; it is usually a query image"]
-        enc = nsu["prepare_full_context_inputs"](queries, ctxs, tok, 8, 64 - 8 - 4, 64, 3)
+        envp = dict(query_text_sequences=queries, context_text_sequences=ctxs, tokenizer=tok, max_query_length=8,
+                    max_context_length=64 - 8 - 4, max_decoder_source_length=64, docs_per_query=3)
+        # :131-153: the two truncate-by-round-trip comprehensions and the query-major pairing loop, as written
+        run_statements(statements_in_lines(pfc, 130, 154), envp, "reference:utils.py:131-153")
+        pairs = envp["concatenated_sequences"]
         rec["pfc.queries"], rec["pfc.contexts"] = np.array(queries), np.array(ctxs)
         rec["pfc.args"] = np.array([8, 64 - 8 - 4, 64, 3])
-        rec["pfc.input_ids"] = enc["input_ids"].numpy()
-        rec["pfc.attention_mask"] = enc["attention_mask"].numpy()
-        rec["pfc.token_type_ids"] = enc["token_type_ids"].numpy()
-        report.append("utils.py:129-167 prepare_full_context_inputs executed with the installed BertTokenizer")
+        rec["pfc.pair_queries"], rec["pfc.pair_contexts"] = np.array([a for a, _ in pairs]), np.array([b for _, b in pairs])
+        report.append("utils.py:131-153 prepare_full_context_inputs: truncation round trips + pairing loop executed with the installed "
+                      "BertTokenizer; :157-165 tokenizer.batch_encode_plus NOT executed (absent from transformers 5.x)")
     except Exception as e:                                       # noqa: BLE001
-        report.append(f"utils.py:129-167 prepare_full_context_inputs NOT executed: {type(e).__name__}: {e}")
+        report.append(f"utils.py:131-153 prepare_full_context_inputs NOT executed: {type(e).__name__}: {e}")
+
+    # ------------------------------------------------------------------ RerankModel.query / FullContextRerankModel.forward glue
+    try:
+        glue_fixture(rec, report, ns_utils_all)
+    except Exception as e:                                       # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        report.append(f"rerank_model.py query()/forward() glue NOT executed: {type(e).__name__}: {e}")
 
     # ------------------------------------------------------------------ HF-internal subclasses: attempted, never adapted
     for rel, what in (("src/models/rerank/attention_fusion.py", "AttentionFusionBertModel"),

@@ -118,3 +118,74 @@ def test_stable_sort_and_recall_precision(ref):
         r0 = fn(raw, pos, Ks)
         assert np.allclose(r0["recall"], ref["met.raw_recall"], atol=0, rtol=1e-15)
         assert np.allclose(r0["precision"], ref["met.raw_precision"], atol=0, rtol=1e-15)
+
+
+def test_query_and_forward_glue_executed_from_the_reference_text(ref):
+    """RerankModel.query (rerank_model.py:345-478) and FullContextRerankModel.forward (:541-590) were executed statement
+    by statement over stock HF modules with seeded weights (make_reference_fixtures.py glue_fixture): mask multiply, first
+    `cross_attn_len` text states for the mapping network's cross-attention, [text | prefix | mapped patches] concat order,
+    L2-normalise, the 128 -> 768 mapping, the attention-mask concat with ones for the vision tokens, both heads, labels and
+    loss.  The oracle must reproduce every stored intermediate (fp32, different operation order inside the HF modules:
+    1e-5; masks exactly)."""
+    import ast as _ast
+    kw = _ast.literal_eval(str(ref["glue.cfg_json"]))
+    cfg = O.OracleConfig(**kw)
+    cfg.loss_fn = "BCE"
+    w = O.make_weights(cfg, seed=int(ref["glue.weight_seed"]), vision=True)
+    wv = O.make_vit_weights(cfg, seed=int(ref["glue.vit_weight_seed"]))
+    Bq, K = int(ref["glue.Bq"]), int(ref["glue.K"])
+    ids, am, tt = (torch.from_numpy(ref[f"glue.{k}"]) for k in ("input_ids", "attention_mask", "token_type_ids"))
+    px = torch.from_numpy(ref["glue.pixel_values"])
+    labels = [float(x) for x in ref["glue.labels"]]
+    with torch.no_grad():
+        cls, pat = O.clip_vision_forward(cfg, wv, px)           # last_hidden_state[:, 0], hidden_states[-2][:, 1:]
+        out = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, cls, pat, labels, want_taps=True)
+        li, qmask = O.query_stage(cfg, w, ids, am, tt, cls.repeat_interleave(K, 0), pat.repeat_interleave(K, 0))
+    want_li = torch.from_numpy(ref["glue.late_interaction_output"])
+    assert li.shape == want_li.shape                          # [N, S + prefix_len + n_patches, li_dim]: the concat order fixes the shape
+    assert (li - want_li).abs().max().item() < 1e-5
+    assert (out.taps["late_interaction"] - want_li).abs().max().item() < 1e-5
+    assert torch.equal(qmask.float().reshape(-1), torch.from_numpy(ref["glue.query_mask"]).reshape(-1))
+    # query_mask comes from id != 0, NOT from the tokenizer's attention mask (the fixture pads with id 0 where the mask is 0)
+    assert torch.equal(qmask.float().reshape(ids.shape), (ids != 0).float())
+    rin = torch.nn.functional.linear(want_li, w["cross_encoder_input_mapping.weight"], w["cross_encoder_input_mapping.bias"])
+    assert (rin - torch.from_numpy(ref["glue.reranker_inputs"])).abs().max().item() < 1e-5
+    P = cfg.prefix_len + cfg.n_patches
+    want_mask = torch.from_numpy(ref["glue.reranker_attention_mask"])
+    assert want_mask.shape == (Bq * K, ids.shape[1] + P)
+    assert torch.equal(want_mask, torch.cat([(ids != 0).float(), torch.ones(Bq * K, P)], 1))
+    assert (out.logits.reshape(-1) - torch.from_numpy(ref["glue.logits"]).reshape(-1)).abs().max().item() < 2e-5
+    assert abs(out.loss.item() - float(ref["glue.loss"])) < 2e-6
+
+
+def test_truncation_round_trip_and_pairing_loop(ref):
+    """utils.py:131-153 executed from the reference's text with the installed BertTokenizer: the product's Python mirror and
+    the native tokenizer (rr_tok_*) must yield the same truncated (query, context) string pairs."""
+    import tempfile
+    from transformers import BertTokenizer
+    from test_pair_tokenizer_cpu import make_vocab
+    from rmr_amd.pair_inputs import NativePairTokenizer, truncate_and_pair
+    vocab = make_vocab()
+    with tempfile.TemporaryDirectory() as d:
+        vp = os.path.join(d, "vocab.txt")
+        open(vp, "w", encoding="utf-8").write("\n".join(vocab) + "\n")
+        tok = BertTokenizer(vp, do_lower_case=True)
+    queries, ctxs = [str(x) for x in ref["pfc.queries"]], [str(x) for x in ref["pfc.contexts"]]
+    mq, mc, _, dpq = (int(x) for x in ref["pfc.args"])
+    want = list(zip((str(x) for x in ref["pfc.pair_queries"]), (str(x) for x in ref["pfc.pair_contexts"])))
+    assert truncate_and_pair(queries, ctxs, tok, mq, mc, dpq) == want
+    nat = NativePairTokenizer(vocab)
+    got = truncate_and_pair(queries, ctxs, types_tokenizer(nat), mq, mc, dpq)
+    assert got == want
+
+
+def types_tokenizer(nat):
+    """HF-style encode/decode facade over the native tokenizer (encode with a token budget, decode of ids)."""
+    class T:
+        def encode(self, text, add_special_tokens=False, max_length=-1, truncation=True):
+            assert not add_special_tokens
+            return nat.encode(text, max_length)
+
+        def decode(self, ids):
+            return nat.decode(ids)
+    return T()
