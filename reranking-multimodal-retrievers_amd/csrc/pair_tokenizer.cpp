@@ -12,7 +12,8 @@
 // WordpieceTokenizer (greedy longest match, 100-character limit), _decode + clean_up_tokenization, prepare_for_model
 // with LONGEST_FIRST truncation and right padding.  tests/test_pair_tokenizer_cpu.py requires ids identical to a Python
 // restatement of the same classes.  Unicode properties come from csrc/unicode_tables.h (generated from Python's
-// unicodedata).  Not done: the NFC pass BasicTokenizer runs before its whitespace split (NFD follows per token).
+// unicodedata).  The NFC pass BasicTokenizer runs before its whitespace split is not needed in the uncased mode (NFD and
+// the mark strip follow per token, NFD(NFC(x)) = NFD(x)); cased vocabularies, where it would matter, are refused.
 #include "../../include/rerank_mi355.h"
 #include "unicode_tables.h"
 
@@ -336,6 +337,10 @@ int rr_tok_create(const char* const* vocab_tokens, int vocab_size, int do_lower_
   try {
     if (!vocab_tokens || vocab_size <= 0 || !out) return RR_ERR_BAD_ARG;
     *out = nullptr;
+    // cased vocabularies are refused: without lower-casing BasicTokenizer does not strip accents either, and its NFC pass
+    // (not implemented here) would then decide the ids of decomposed input.  Uncased: NFD(NFC(x)) = NFD(x), the pass is moot
+    // (tests/test_pair_tokenizer_cpu.py::test_decomposed_and_composed_input_tokenise_alike).  The reference is uncased.
+    if (!do_lower_case) return RR_ERR_UNSUPPORTED;
     auto* t = new rr_tokenizer();
     t->lower = do_lower_case != 0;
     t->inv.reserve(vocab_size);

@@ -47,14 +47,23 @@ class _GatherPlan:
             self.full = torch.empty(heads * n_pairs, dtype=dtype, device=device)
 
 
-_PLANS: Dict[tuple, _GatherPlan] = {}
+_PLANS: "OrderedDict[tuple, _GatherPlan]" = None      # small LRU: a serving loop sees a handful of batch sizes (the full one, the last one)
+_MAX_PLANS = 8
 
 
-def _plan(device, dtype, world, n_pairs, heads) -> _GatherPlan:
-    key = (str(device), dtype, world, n_pairs, heads)
+def _plan(device, dtype, world, n_pairs, heads, group=None) -> _GatherPlan:
+    from collections import OrderedDict
+    global _PLANS
+    if _PLANS is None:
+        _PLANS = OrderedDict()
+    key = (str(device), dtype, world, n_pairs, heads, id(group) if group is not None else 0)
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = _GatherPlan(device, dtype, world, n_pairs, heads)
+        while len(_PLANS) > _MAX_PLANS:
+            _PLANS.popitem(last=False)
+    else:
+        _PLANS.move_to_end(key)
     return p
 
 
@@ -64,7 +73,7 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
     next call with the same shape overwrites."""
     world = dist.get_world_size(group)
     heads = 1 if local2 is None else 2
-    p = _plan(local.device, local.dtype, world, n_pairs, heads)
+    p = _plan(local.device, local.dtype, world, n_pairs, heads, group)
     n_loc = local.numel()
     p.send[:n_loc].copy_(local.reshape(-1))
     if local2 is not None:
@@ -121,9 +130,11 @@ def sharded_forward(engine, input_ids, attention_mask, token_type_ids, Bq: int, 
 
     def head(l1, l2):
         out = engine.head(l1, l2, labels, Bq, K, want_scores=want_scores, want_order=True)
-        out["logits"] = l1
+        # the gathered vectors are views of the exchange buffers, which the next call of the same shape overwrites: hand the
+        # caller its own N floats (an eval loop keeps the outputs of many batches)
+        out["logits"] = l1.clone()
         if l2 is not None:
-            out["logits2"] = l2
+            out["logits2"] = l2.clone()
         return out
 
     return ShardedReranker(encode, head, group)(N)

@@ -140,3 +140,18 @@ def test_errors(native):
         native.prepare_full_context_inputs(["a"], ["b", "c"], 4, 4, 16, 3)
     with pytest.raises(ValueError):
         native.prepare_full_context_inputs(["a"], ["b"], 4, 4, 2, 1)      # max_length < 3
+    with pytest.raises(NotImplementedError):
+        NativePairTokenizer(make_vocab(), do_lower_case=False)            # cased: would need the NFC pass (not built)
+
+
+def test_decomposed_and_composed_input_tokenise_alike(native, oracle):
+    """HF 4.38 `BasicTokenizer.tokenize` runs an NFC pass before its whitespace split; the native tokenizer does not.  In
+    the uncased mode the reference uses (bert-base-uncased, do_lower_case=True) every token is NFD-decomposed and stripped
+    of its marks right after, and NFD(NFC(x)) = NFD(x) for every string (canonical equivalence), so the pass cannot change
+    an id: checked here on the mixed-script corpus fed composed (NFC), decomposed (NFD) and as written.  The cased mode,
+    where the pass would matter, is refused by rr_tok_create (test_errors)."""
+    import unicodedata
+    for t in corpus(300, seed=77, avoid=("\x00",)):           # (a C string ends at NUL)
+        want = oracle.encode(unicodedata.normalize("NFC", t))
+        for form in (t, unicodedata.normalize("NFD", t), unicodedata.normalize("NFC", t)):
+            assert native.encode(form) == want, repr(form)
