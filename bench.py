@@ -74,6 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks time-share cuda:0 and exchange over gloo: exercises the spawn / shard / gather / head "
                          "path with the real engine on a one-GPU box; the line is marked, it is NOT a scaling measurement")
+    ap.add_argument("--weights-gain", type=float, default=1.0,
+                    help="std multiplier of the Linear matrices of the synthetic weights (1 = HF init: near-uniform attention; 2.5 = the "
+                         "peaked-attention regime of tests/golden c3_sep).  The line then also reports how many attention workgroups "
+                         "the fixed-reference schedule had to recompute online (`attention_redo`)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="process-wide A/B switch of the library (rr_set_tuning), e.g. --tuning ln_fold=0; diagnostic")
     a = ap.parse_args(argv)
@@ -252,7 +256,7 @@ def main():
     for kv in args.tuning:
         k, v = kv.split("=")
         assert rmr_amd._lib.load().rr_set_tuning(k.encode(), int(v)) == 0, kv
-    sd = rmr_amd.synthetic_state_dict(arch, seed=0, hf_init=True)
+    sd = rmr_amd.synthetic_state_dict(arch, seed=0, hf_init=True, gain=args.weights_gain)
     eng = rmr_amd.RerankEngine(arch, dev)
     eng.load_state_dict(sd)
 
@@ -280,6 +284,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    redo = None
+    if args.weights_gain != 1.0:      # one untimed step with the redo counters on: how often the fixed-reference attention falls back
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        rmr_amd._lib.load().rr_set_attn_redo_stats(cnt.data_ptr())
+        step()
+        fence()
+        rmr_amd._lib.load().rr_set_attn_redo_stats(0)
+        redo = {"workgroups_recomputed_online": int(cnt[0]), "workgroups": int(cnt[1]),
+                "fraction": float(cnt[0]) / max(1, int(cnt[1])), "weights_gain": args.weights_gain,
+                "note": "fixed-reference attention: a workgroup whose row sum leaves the operand type's range (or that sees no valid "
+                        "key) is recomputed with the online softmax by the second launch; counted over one step"}
     eng.set_profiling(not args.no_profile)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -322,7 +337,8 @@ def main():
                                        "1 RCCL all-gather of logits/step") if distributed else
                                       "1 GPU, no process group, no collective (the N > 1 legs shard the pairs over ranks with one "
                                       "RCCL all-gather of logits per step)",
-                       "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"},
+                       "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"
+                                  + (f"; Linear matrices widened x{args.weights_gain} (peaked attention)" if args.weights_gain != 1.0 else "")},
             "step_ms_device": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
                                "n": len(step_ms), "note": "HIP events around each timed step on the work stream, rank 0"},
             "parity": {"bf16": "|logit - fp32 stock-HF| <= max(1e-3, the bf16-autocast reference's own drift) on every golden "
@@ -333,6 +349,8 @@ def main():
             "whole_path_tflops_per_gpu": pairs_per_s * fpp / 1e12 / world,
             "whole_path_frac_of_bf16_peak": pairs_per_s * fpp / 1e12 / world / PEAK_BF16_TFLOPS,
         }
+        if redo is not None:
+            res["attention_redo"] = redo
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0

@@ -368,6 +368,7 @@ int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */
+int rr_set_attn_redo_stats(void* device_buf);   /* diagnostic: DEVICE 2 x uint64 — the redo launches of the fixed-reference attention add (workgroups flagged for the online recompute, workgroups looked at) — or NULL */
 int rr_set_gemm_stagger(int unit);   /* start skew of the first dispatch wave, in s_sleep(127) units; 0 = off */
 int rr_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                     float* out_f32, uint16_t* out_bf16, void* hip_stream);

@@ -89,6 +89,7 @@ _SIGS = {
     "rr_util_quantize_rows_e4m3": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rr_set_attn_stamps": (C.c_int, [_P]),
+    "rr_set_attn_redo_stats": (C.c_int, [_P]),
     "rr_tok_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rr_tok_destroy": (C.c_int, [C.c_void_p]),
     "rr_tok_encode": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _P, C.c_int]),

@@ -145,6 +145,7 @@ struct AttnArgs {
   const float* dense_bias; int dense_ld;
   unsigned long long* stamps; int tuning;
   int* flags; int nblk;      // fixed-reference schedule: one word per workgroup of the grid, 1 = recompute online
+  unsigned long long* redo_stats;   // diagnostic (rr_set_attn_redo_stats): [0] += flagged workgroups, [1] += workgroups looked at; nullptr in production
 };
 
 // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
@@ -701,6 +702,10 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   if (threadIdx.x < REDO_SPAN && id < a.nblk && a.flags[id]) list[atomicAdd(&count, 1)] = id;
   __syncthreads();
   const int n = __builtin_amdgcn_readfirstlane(count);
+  if (a.redo_stats && threadIdx.x == 0) {
+    atomicAdd(&a.redo_stats[0], (unsigned long long)n);
+    atomicAdd(&a.redo_stats[1], (unsigned long long)min(REDO_SPAN, a.nblk - (int)blockIdx.x * REDO_SPAN));
+  }
   for (int j = 0; j < n; ++j) {     // workgroups are independent: the order inside the list does not matter
     int grp, qblk;
     if (!block_map(__builtin_amdgcn_readfirstlane(list[j]), (a.Tq + 128 * SPLIT - 1) / (128 * SPLIT), a.groups, grp, qblk)) continue;
@@ -725,6 +730,11 @@ extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; 
 extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 3) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
+  return 0;
+}
+static unsigned long long* g_attn_redo_stats = nullptr;
+extern "C" int rr_set_attn_redo_stats(void* device_buf) {   // diagnostic: 2 x uint64 (flagged, looked at) accumulated by the redo launches, or NULL
+  g_attn_redo_stats = (unsigned long long*)device_buf;
   return 0;
 }
 
@@ -779,7 +789,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (dense_bias && (dense_ld < Tk || (dense_ld & 63))) return hipErrorInvalidValue;
   const dim3 grid((unsigned)nblk), block(256);
   AttnArgs a{q, q_stride, q_batch_div, q_batch_off, k, v, kv_stride, key_bias, heads, Tq, Tk, out, out_stride, (int)groups,
-             dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk};
+             dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk, g_attn_redo_stats};
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
   if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {

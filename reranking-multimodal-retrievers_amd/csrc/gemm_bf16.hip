@@ -849,6 +849,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   }
   stamp(stamps, 0);
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
+  // FOLD on a 16-bit / fp32-output GEMM: consumer side of the folded LayerNorm; on the fp32-stream residual GEMM (SPLIT 0):
+  // producer side (x16 rows + statistics partials).  Compile-time, so that the residual GEMMs that emit nothing (fp8 mode,
+  // plain residual launches) carry no reduction code and no registers for it.
+  constexpr bool FOLD_IN = FOLD && EPI != EPI_BIAS_RESID_F32, FOLD_OUT = FOLD && EPI == EPI_BIAS_RESID_F32;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   // persistent XCD-aware walk: workgroup (xcd = bid & 7, j = bid >> 3) takes the tiles chunk0 + j + i * (grid / 8) of its
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     int lane_ = lane;
     asm volatile("" : "+v"(lane_));     // opaque: the per-lane offsets below are recomputed here (a dozen VALU per tile), not hoisted out of the tile loop and spilled
     const int lane = lane_;
-    if constexpr (FOLD) {
+    if constexpr (FOLD_IN) {
       const int d = wave * 64 + lane;                                   // dword d of the 256 x float2 block
       glds4_so(ln.in_stats + m0_, (uint32_t)((min(d >> 1, M - 1 - m0_) * 2 + (d & 1)) * 4),
                __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + wave * 256));
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     if (wave < 4) {
       if (bias) glds4_so(bias + n0_, (uint32_t)(min(wave * 64 + lane, N - 1 - n0_) * 4),
                          __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 2048 + wave * 256));
-    } else if (FOLD) {
+    } else if (FOLD_IN) {
       glds4_so(ln.csum + n0_, (uint32_t)(min((wave - 4) * 64 + lane, N - 1 - n0_) * 4),
                __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 3072 + (wave - 4) * 256));
     }
@@ -1191,7 +1195,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     // The parameter reads run one (quadrant, column block) step ahead of the arithmetic that consumes them, pinned with
     // scheduling fences: left free, hipcc hoists all 16 ds_read_b128 (64 registers) to the top of the section, which at
     // 128 live accumulators spills the main loop's carried registers around it.
-    if constexpr (FOLD) {
+    if constexpr (FOLD_IN) {
       // folded LayerNorm, consumer side: A held raw pre-LayerNorm rows; (mean, rstd) of the 8 rows this lane owns
       float2 fst[2][4];
 #pragma unroll
@@ -1465,7 +1469,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           }
           // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
           // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)
-          if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N);
+          if constexpr (FOLD_OUT) { if (ln.x16) fold_emit<DT>(ln, f, ok, gm, gcol, N); }
         }
         RR_SBAR();
       }
@@ -1608,7 +1612,12 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
     RR_GEMM_CASE_FOLD(EPI_BIAS_GELU_BF16)
     RR_GEMM_CASE_FOLD(EPI_BIAS_F32)
     RR_GEMM_CASE(EPI_BIAS_TANH_BF16)
-    RR_GEMM_CASE(EPI_BIAS_RESID_F32)
+    case EPI_BIAS_RESID_F32: {                               /* fp32 stream: with / without the folded-LayerNorm producer outputs */
+      if (ln.in_stats) return hipErrorInvalidValue;
+      if (ln.x16) RR_GEMM_CASE_F(EPI_BIAS_RESID_F32, true)
+      else RR_GEMM_CASE_F(EPI_BIAS_RESID_F32, false)
+      break;
+    }
     RR_GEMM_CASE(EPI_BIAS_QGELU_BF16)
     default: return hipErrorInvalidValue;
   }
@@ -1639,7 +1648,7 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     return hipGetLastError();                                                                                             \
   }
   if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
-  if (epilogue == EPI_BIAS_RESID_F32 && split == 0) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0, false)
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 0 && !ln.x16) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0, false)
   if (epilogue == EPI_BIAS_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0, true)
   if (epilogue == EPI_BIAS_GELU_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0, true)
 #undef RR_DIAG_LAUNCH

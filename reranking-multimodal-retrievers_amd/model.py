@@ -163,16 +163,17 @@ def vit_weight_spec(a: dict) -> List[tuple]:
     return s
 
 
-def synthetic_state_dict(a: dict, seed: int = 0, hf_init: bool = True) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(a: dict, seed: int = 0, hf_init: bool = True, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded random-init weights (HF init: N(0, 0.02) matrices/embeddings, LN 1/0, zero biases —
     modeling_flmr.py:199-214) for benchmarks: there are no checkpoints in the build environment.
     Each tensor has its own generator seeded by (seed, index), identical to the test oracle's scheme so the
-    CPU baseline can be fed the very same weights."""
+    CPU baseline can be fed the very same weights.  `gain` > 1 widens the Linear matrices only (the oracle's make_weights
+    does the same): at 2.5 attention is peaked and a candidate list spreads over ~0.2 in logit, as in tests/golden c3_sep."""
     w = {}
     for idx, (name, shape, kind) in enumerate(weight_spec(a)):
         g = torch.Generator().manual_seed(seed * 1000003 + idx)
         if kind in ("w", "e"):
-            t = torch.randn(shape, generator=g) * 0.02
+            t = torch.randn(shape, generator=g) * (0.02 * (gain if kind == "w" else 1.0))
         elif kind == "g":
             t = torch.ones(shape) if hf_init else 1.0 + 0.1 * torch.randn(shape, generator=g)
         else:

@@ -61,9 +61,14 @@ def test_recall_at_5_and_top5_sets_match_the_fp32_reference(dt):
     exactly as the fp32 reference ranks them, Recall@10 = 1 for both, and the device order is the stable descending sort
     of the device logits."""
     import rmr_amd
+    from rmr_amd import _lib
     cfg, w, vision, qs = load_fullsize("c3_sep")
     eng = _engine(cfg, vision, w, dt)
     ranked, pos, ranked_ref = [], [], []
+    # c3_sep's widened weights (gain 2.5) give PEAKED attention: the case in which the fixed-reference schedule (100 pairs x 12
+    # heads x 4-5 query blocks >= 1 024 workgroups: it is the one that runs here) may have to recompute workgroups online
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _lib.load().rr_set_attn_redo_stats(cnt.data_ptr())
     for qi, q in enumerate(qs):
         sel = torch.from_numpy(q["selected"].astype(np.int64))
         assert float(q["gap_5_6"]) >= 0.08
@@ -83,6 +88,11 @@ def test_recall_at_5_and_top5_sets_match_the_fp32_reference(dt):
         ranked.append(order)
         ranked_ref.append(ref_order)
         pos.append([int(q["positive_list_index"])])
+    torch.cuda.synchronize()
+    _lib.load().rr_set_attn_redo_stats(0)
+    record_margin(f"c3_sep/{dt}/attention_redo", workgroups_recomputed_online=int(cnt[0]), workgroups=int(cnt[1]),
+                  fraction=float(cnt[0]) / max(1, int(cnt[1])))
+    assert int(cnt[1]) > 0                                     # the fixed-reference schedule ran
     got = rmr_amd.recall_precision_at_k(ranked, pos, [5, 10])
     want = O.recall_precision_at_k(ranked_ref, pos, [5, 10])
     assert got == want

@@ -19,18 +19,26 @@ sys.path.insert(0, %r)
 import torch
 from rmr_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+import ctypes
+_probe = ctypes.CDLL(_lib.LIB_PATH)                       # an older build lacks the newest diagnostic entry points: bind what it has
+_lib._SIGS = {k: v for k, v in _lib._SIGS.items() if hasattr(_probe, k)}
 import rmr_amd
 from rmr_amd.synthetic import image_features, pair_batch
 lib = _lib.load()
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
     assert lib.rr_set_tuning(k.encode(), int(v)) == 0, kv
-arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750, loss_fn="BCE"), compute_dtype=os.environ.get("RR_DTYPE", "fp16"))
+wl = os.environ.get("RR_WORKLOAD", "c3")                 # c3 (default) | c5 (bert-large, K = 200, text-only) | c5fp8
+shape = dict(hidden=1024, layers=24, heads=16, intermediate=4096, ce_hidden=1024, ce_heads=16, ce_intermediate=4096) if wl.startswith("c5") else {}
+arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750, loss_fn="BCE"),
+                         has_vision=int(wl == "c3"), compute_dtype=os.environ.get("RR_DTYPE", "fp16"), **shape)
+if wl == "c5fp8":
+    arch["fp8"] = 1
 eng = rmr_amd.RerankEngine(arch)
 eng.load_state_dict(rmr_amd.synthetic_state_dict(arch, 0, True))
-Bq, K, S = 8, 100, 512
+Bq, K, S = (8, 100, 512) if wl == "c3" else (4, 200, 512)
 ids, am, tt = [t.cuda() for t in pair_batch(arch["vocab_size"], Bq, K, S, regime=os.environ.get("RR_REGIME", "full"))]
-cls, pat = [t.cuda() for t in image_features(Bq, 49, 768)]
+cls, pat = [t.cuda() for t in image_features(Bq, 49, 768)] if wl == "c3" else (None, None)
 ts = []
 for r in range(int(sys.argv[2]) + 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
