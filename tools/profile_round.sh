@@ -7,8 +7,8 @@ root=$(pwd)
 out=$root/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="python3 $root/bench.py"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -o kt -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-alt-dtype > $out/${tag}_c3_bench_under_rocprof.json 2> $out/${tag}_kt.err
+B="python3 $root/bench.py $BENCH_ARGS"     # BENCH_ARGS="--workload c5 --fp8" profiles another workload (tag it accordingly)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt -o kt -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-alt-dtype > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_kt.err
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_f -o f -- $B --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-e2e --no-alt-dtype > /dev/null 2> $out/${tag}_pmc_f.err
 echo "fetch done"
@@ -21,7 +21,7 @@ echo "sq2 done"
 cd $root
 python3 tools/pmc_traffic.py $out/${tag}_pmc_f $out/${tag}_pmc_w > $out/${tag}_hbm_traffic.json
 python3 tools/sq_counters.py $out/${tag}_sq1 $out/${tag}_sq2 > $out/${tag}_sq_counters.json
-cp $(find $out/${tag}_kt -name "*kernel_stats.csv" | head -1) $out/${tag}_c3_kernel_stats.csv
+cp $(find $out/${tag}_kt -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # the raw per-dispatch CSVs are large: keep the summaries only
 rm -rf $out/${tag}_kt $out/${tag}_pmc_f $out/${tag}_pmc_w $out/${tag}_sq1 $out/${tag}_sq2
 echo "summaries written"
