@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks time-share cuda:0 and exchange over gloo: exercises the spawn / shard / gather / head "
                          "path with the real engine on a one-GPU box; the line is marked, it is NOT a scaling measurement")
+    ap.add_argument("--bucketed", action="store_true",
+                    help="length-bucketed execution (RerankEngine.forward_ids_bucketed): with --regime realistic the pairs run at the "
+                         "row length of their bucket instead of the padded seq_len; pairs/s still counts padded pairs (the contract)")
     ap.add_argument("--weights-gain", type=float, default=1.0,
                     help="std multiplier of the Linear matrices of the synthetic weights (1 = HF init: near-uniform attention; 2.5 = the "
                          "peaked-attention regime of tests/golden c3_sep).  The line then also reports how many attention workgroups "
@@ -274,6 +277,8 @@ def main():
     def step():
         if distributed:      # also with one rank: the same slice -> all-gather -> head path the N-GPU runs take
             return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None, want_scores=True)
+        if args.bucketed:
+            return eng.forward_ids_bucketed(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
         return eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
 
     def fence():
@@ -331,6 +336,8 @@ def main():
             "config": {"workload": (names[wl] if not args.text_only else "c3-text: text-only cross-encoder rerank (Lc=1)")
                        + f", K={K}, seq_len={S}, vision_tokens={P}",
                        "queries_per_step": Bq, "pairs_per_step": N, "token_regime": args.regime,
+                       **({"execution": f"length-bucketed: {int(out['bucket_rows'])} of {N * S} padded rows computed per step"}
+                          if args.bucketed else {}),
                        "parallelism": (f"REHEARSAL: {world} ranks time-sharing ONE GPU, logits exchanged over gloo through the host; "
                                        "not a scaling measurement") if args.rehearse_one_gpu else
                                       (f"pairs sharded over {world} GPU(s) ({nranks_seen} ranks in the process group), "

@@ -162,6 +162,15 @@ int64_t rr_workspace_bytes(rr_handle h, int n_pairs, int seq_len);
  * (PyTorch's caching allocator). */
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream);
 
+/* Length-bucketed execution (SURVEY.md "Variable length"; the reference pads every pair to max_decoder_source_length,
+ * utils.py:157-165).  After rr_set_padded_seq_len(h, S_pad) a full-context rr_forward may be called with a seq_len S <= S_pad —
+ * the host hands over only the first S columns of the pairs whose real length fits — and computes what the S_pad-long call
+ * computes for those pairs: text positions are 0..S-1 either way, padded keys contribute exactly 0 to every softmax, and the
+ * vision tokens of the cross-encoder keep the positions S_pad.. they have behind the padded text.  Text-only models: logits bit
+ * for bit those of the padded call; with vision tokens the cross-encoder's key tiles are cut at other places, i.e. equal up to
+ * fp32 summation order.  0 switches it off.  Python: RerankEngine.forward_ids_bucketed. */
+int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
+
 /* rr_forward: one pass of the hot path over N = Bq*K (query,candidate) pairs.
  *   input_ids, attention_mask, token_type_ids : DEVICE int64 [N,S] row-major, query-major pair order
  *       (prepare_full_context_inputs, utils.py:129-167).  attention_mask masks keys in the text

@@ -58,6 +58,7 @@ _SIGS = {
     "rr_num_required_weights": (C.c_int, [_P]),
     "rr_required_weight_name": (C.c_char_p, [_P, C.c_int]),
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
+    "rr_set_padded_seq_len": (C.c_int, [_P, C.c_int]),
     "rr_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rr_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                              _P, _P, _P, _P, _P, _P]),

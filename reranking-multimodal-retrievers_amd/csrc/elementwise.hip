@@ -190,19 +190,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
   ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols, dt);
 }
 
-// ---- cross-encoder embeddings from inputs_embeds: x + type[0] + pos[t] -> LN  (row = pair*T + t)
+// ---- cross-encoder embeddings from inputs_embeds: x + type[0] + pos[p(t)] -> LN  (row = pair*T + t).  p(t) = t, except in a
+// length-bucketed forward (rr_set_padded_seq_len): the pair's text occupies t < s_text and the tokens behind it (vision
+// prefix + patches) keep the positions they have behind the PADDED text, vis_pos0 + (t - s_text).
 __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                           const float* __restrict__ type0,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, int rows, int T,
                                                           int cols, float* __restrict__ o32, bf16_t* __restrict__ o16,
-                                                          int dt) {
+                                                          int dt, int s_text, int vis_pos0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int n4 = cols >> 2;
   const float4* xr = (const float4*)(x + (size_t)row * cols);
-  const float4* pr = (const float4*)(pos + (size_t)(row % T) * cols);
+  const int t = row % T, pt = t < s_text ? t : vis_pos0 + (t - s_text);
+  const float4* pr = (const float4*)(pos + (size_t)pt * cols);
   const float4* tr = (const float4*)type0;
   float4 v[MAX_V4];
 #pragma unroll
@@ -541,10 +544,11 @@ hipError_t rr_launch_embed_ln(const int64_t* ids, const int64_t* tts, const floa
 
 hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* type0, const float* gamma,
                                  const float* beta, float eps, int rows, int T, int cols, float* o32, bf16_t* o16,
-                                 int dt, hipStream_t st) {
+                                 int dt, hipStream_t st, int s_text, int vis_pos0) {
   if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
+  if (s_text < 0 || s_text > T) { s_text = T; vis_pos0 = T; }     // plain positions 0 .. T-1
   hipLaunchKernelGGL(ce_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, pos, type0, gamma, beta, eps,
-                     rows, T, cols, o32, o16, dt);
+                     rows, T, cols, o32, o16, dt, s_text, vis_pos0);
   return hipGetLastError();
 }
 

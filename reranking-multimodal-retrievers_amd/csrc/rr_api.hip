@@ -21,7 +21,7 @@
 hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*,
                               const float*, float, int, int, int, int, int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
-                                 int, float*, bf16_t*, int, hipStream_t);
+                                 int, float*, bf16_t*, int, hipStream_t, int s_text = -1, int vis_pos0 = 0);
 hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
                                   int, int, const float*, int, int, hipStream_t);
 hipError_t rr_launch_joint_masks(const int64_t*, const int64_t*, int, int, int, int, long long, float*, float*, float*,
@@ -178,6 +178,7 @@ struct rr_model {
   // workspace (grow-only)
   char* ws = nullptr;
   size_t ws_cap = 0;
+  int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
   bool pinned_blocks = false;          // rr_reserve was called or a stream capture was seen: outgrown blocks are retired, not freed
   std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
 
@@ -888,12 +889,14 @@ int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K,
 
 // CrossEncoder over AttentionFusionBertModel (utils.py:85-108, attention_fusion.py:61-160): Linear(D -> Hc) ->
 // embeddings(inputs_embeds) -> Lc layers.  Input: w.li16 [n*T, D], w.ce_bias [n, T]; output: w.h32 [n*T, Hc].
-int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const float* adj = nullptr, int adj_ld = 0) {
+int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const float* adj = nullptr, int adj_ld = 0,
+                      int s_text = -1, int vis_pos0 = 0) {
   const rr_config& c = m->cfg;
   const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate, RT = n * T;
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
   RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
-         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st));
+         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st,
+                               s_text, vis_pos0));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
     int folded = OP_NORMALISED;
@@ -1276,6 +1279,16 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   const int P = vision ? c.prefix_len + c.n_patches : 0, T = S + P;
   if (T > c.ce_max_pos)
     return fail(m, RR_ERR_BAD_SHAPE, "cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", T, c.ce_max_pos);
+  // length-bucketed forward (rr_set_padded_seq_len): S is this call's (shorter) row length, the cross-encoder positions of the
+  // vision tokens are those behind the padded text
+  int s_text = -1, vis_pos0 = 0;
+  if (m->padded_S > 0 && !joint && S != m->padded_S) {
+    if (S > m->padded_S) return fail(m, RR_ERR_BAD_SHAPE, "seq_len %d exceeds the padded length %d set by rr_set_padded_seq_len", S, m->padded_S);
+    if (m->padded_S + P > c.ce_max_pos)
+      return fail(m, RR_ERR_BAD_SHAPE, "padded cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", m->padded_S + P, c.ce_max_pos);
+    s_text = S;
+    vis_pos0 = m->padded_S;
+  }
   const bool full = pair_begin == 0 && pair_end == N;
   if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && labels)
     return fail(m, RR_ERR_BAD_ARG, "Labels should not be provided for negative sampling loss function");
@@ -1420,7 +1433,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
            rr_launch_fusion_adj(preflmr_scores, S, q_len + P, S - q_len, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st));
     adj = m->adj;
   }
-  RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld));
+  RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld, s_text, vis_pos0));
   return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
                    loss_out, scores_out, order_out, joint != 0);
 }
@@ -1885,6 +1898,14 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host) {
   if (!w_host || !out_host || !scales_host || rows <= 0 || cols <= 0) return RR_ERR_BAD_ARG;
   return guarded(nullptr, [&]() -> int { host_quantize_rows(w_host, (size_t)rows, (size_t)cols, out_host, scales_host); return RR_OK; });
+}
+int rr_set_padded_seq_len(rr_handle h, int padded_seq_len) {
+  if (!h || padded_seq_len < 0) return RR_ERR_BAD_ARG;
+  return guarded(h, [&]() -> int {
+    if (padded_seq_len > h->cfg.max_pos) return fail(h, RR_ERR_BAD_SHAPE, "padded_seq_len %d exceeds max_position_embeddings %d", padded_seq_len, h->cfg.max_pos);
+    h->padded_S = padded_seq_len;
+    return RR_OK;
+  });
 }
 int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, int with_fusion, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_reserve_impl(h, n_pairs, n_queries, len_a, len_b, with_fusion, hip_stream); });

@@ -494,6 +494,39 @@ def test_graph_replay_survives_a_later_larger_forward():
         assert torch.equal(again["logits"], ref_logits)
 
 
+@pytest.mark.parametrize("name", ["c2", "tiny_mm"])
+def test_length_bucketed_forward_equals_the_padded_forward(name):
+    """RerankEngine.forward_ids_bucketed (rr_set_padded_seq_len): pairs grouped by the smallest bucket that holds their real
+    length and run at that row length must give the padded forward's logits — bit for bit for a text-only model (same rows,
+    padded keys contribute exact zeros, same key tiles), up to fp32 summation order in the cross-encoder's attention when
+    vision tokens follow the text (their keys land in other tiles) — and the same loss and rank order."""
+    g = load_golden(name)
+    cfg, vision = g["cfg"], g["vision"]
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    eng = _engine(cfg, vision, w, "fp16")
+    Bq, K, S = 3, 7, g["S"]
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=31, regime="realistic")
+    lens = (ids != 0).sum(1)
+    assert lens.min().item() <= S // 2 < lens.max().item()                 # the batch really spans several buckets
+    img = O.make_image_feats(cfg, Bq, seed=31) if vision else (None, None)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K, None if img[0] is None else img[0].cuda(), None if img[1] is None else img[1].cuda())
+    ref = eng.forward_ids(*args, None, want_order=True)
+    buckets = (S // 4, S // 2, 3 * S // 4)
+    got = eng.forward_ids_bucketed(*args, None, buckets=buckets, want_order=True)
+    torch.cuda.synchronize()
+    assert got["bucket_rows"] < Bq * K * S
+    if vision:
+        assert (got["logits"] - ref["logits"]).abs().max().item() < 5e-5
+    else:
+        assert torch.equal(got["logits"], ref["logits"])
+        assert torch.equal(got["order"], ref["order"])
+    assert abs(got["loss"].item() - ref["loss"].item()) < 1e-5
+    # and the handle is back to plain positions afterwards
+    again = eng.forward_ids(*args, None, want_order=True)
+    torch.cuda.synchronize()
+    assert torch.equal(again["logits"], ref["logits"])
+
+
 def test_lightning_checkpoint_keys_load_through_the_prefix():
     """Reranker_base_executor.py:351-381 loads `checkpoint['state_dict']` with strict=False: keys carry the executor's
     `reranker.` prefix, tensors may be bf16/fp16 (mixed-precision checkpoints), and unrelated entries (optimizer/metric
