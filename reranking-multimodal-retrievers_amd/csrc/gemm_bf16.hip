@@ -1350,12 +1350,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           const int r = (tid >> 5) + u * 16, gm = row_base + r;
           const bool ok = gm < M && col_ok;
           float x[8];
-          if constexpr ((SPLIT & 1) != 0) {      // x = hi (operand type) + lo (fp16)
+          if constexpr ((SPLIT & 1) != 0) {      // x = hi (operand type) + lo (fp16): one v_fma_mix_f32 per element (rr_common.h)
+            const uint32_t tok = mix_fence(rh[u], rl[u]);
             const uint32_t hw[4] = {rh[u].x, rh[u].y, rh[u].z, rh[u].w}, lw[4] = {rl[u].x, rl[u].y, rl[u].z, rl[u].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float2 h = unpack2<DT>(hw[j]), l = unpack2<1>(lw[j]);
-              x[2 * j] = h.x + l.x; x[2 * j + 1] = h.y + l.y;
+              if constexpr (DT == 1) {
+                x[2 * j] = mix_add_f16<0>(hw[j], lw[j], tok); x[2 * j + 1] = mix_add_f16<1>(hw[j], lw[j], tok);
+              } else {
+                const float2 h = unpack2<0>(hw[j]);
+                x[2 * j] = mix_add_f16_f32<0>(h.x, lw[j], tok); x[2 * j + 1] = mix_add_f16_f32<1>(h.y, lw[j], tok);
+              }
             }
           } else {
             x[0] = ra[u].x; x[1] = ra[u].y; x[2] = ra[u].z; x[3] = ra[u].w;
@@ -1383,8 +1388,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
               uint32_t lo[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const float2 hb = unpack2<DT>(hi[j]);
-                lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
+                if constexpr (DT == 1) {
+                  lo[j] = pack2<1>(mix_sub_f16<0>(f[2 * j], hi[j]), mix_sub_f16<1>(f[2 * j + 1], hi[j]));
+                } else {
+                  const float2 hb = unpack2<0>(hi[j]);
+                  lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
+                }
               }
               *(uint4*)(ln.lo_out + (size_t)gm * ln.ld16 + gcol) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             } else {

@@ -51,6 +51,42 @@ __device__ __forceinline__ float2 unpack2(uint32_t u) {
     return make_float2((float)v[0], (float)v[1]);
   }
 }
+// v_fma_mix_f32 (fp32 multiply-add whose operands may be the halves of packed fp16 registers): float(h) + float(l) and
+// f - float(h) in ONE instruction each instead of convert + convert + add / convert + subtract.  h * 1.0 and h * -1.0 are
+// exact, so the results are bit for bit those of the separate instructions.  hipcc does not form it from C++ (it emits
+// v_cvt_f32_f16 + v_add_f32).  HALF: 0 = low, 1 = high half of the packed word.  VOP3P like the packed-f32 ops of the
+// stale-lane hazard (DESIGN.md "Numerics"): a caller that feeds freshly loaded registers fences them first (mix_fence).
+// `tok` (mix_fence) is an ordering-only operand: it ties the instruction behind the fence of the loads it reads.
+template <int HALF>
+__device__ __forceinline__ float mix_add_f16(uint32_t h, uint32_t l, uint32_t tok) {
+  float d;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(l), "v"(tok));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(l), "v"(tok));
+  return d;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_add_f16_f32(float h, uint32_t l, uint32_t tok) {      // h (fp32) + float(half of l)
+  float d;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(l), "v"(h), "v"(tok));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(l), "v"(h), "v"(tok));
+  return d;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_sub_f16(float f, uint32_t h) {           // f - float(half of h)
+  float d;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(f));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(f));
+  return d;
+}
+// Two wait states between a counted vmcnt release of freshly loaded registers and their first VOP3P reader.  The loaded
+// registers are INPUTS only (as in/out operands of an asm statement hipcc copied them out of the load destinations, with a
+// vmcnt(0) behind every load: the next pass's residual loads became synchronous, 4.9k -> 36k cycles per tile); the
+// returned token orders the readers behind the fence.
+__device__ __forceinline__ uint32_t mix_fence(const uint4& a, const uint4& b) {
+  uint32_t t;
+  asm volatile("s_nop 1\n\tv_mov_b32 %0, 0" : "=v"(t) : "v"(a.x), "v"(b.x));
+  return t;
+}
 __device__ __forceinline__ uint32_t pack2rt(float lo, float hi, int dt) { return dt ? pack2<1>(lo, hi) : pack2<0>(lo, hi); }
 template <int DT>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
