@@ -132,7 +132,7 @@ def archived_pmc():
     and were taken on the headline workload (c3) only."""
     import glob
     out = {"note": "archived rocprofv3 --pmc passes of `python bench.py` (c3) on an earlier MI355X box; not measured in this run"}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")) if "_c5" not in os.path.basename(f))
     if files:
         try:
             d = json.load(open(files[-1]))["per_kernel_class"]["gemm"]
@@ -140,7 +140,7 @@ def archived_pmc():
             out["traffic_source"] = os.path.relpath(files[-1], ROOT)
         except Exception:
             pass
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")) if "_c5" not in os.path.basename(f))
     if files:
         try:
             d = json.load(open(files[-1]))

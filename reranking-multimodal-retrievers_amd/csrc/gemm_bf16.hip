@@ -148,7 +148,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // lane of the wave must call this (the reductions are cross-lane); `valid` masks rows/columns outside the matrix.
 template <int DT>
 __device__ __forceinline__ void fold_emit(const LnResid& ln, float4 f, bool valid, int gm, int gcol, int N) {
-  if (valid) *(uint2*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint2(pack2<DT>(f.x, f.y), pack2<DT>(f.z, f.w));
+  if (valid) store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint2(pack2<DT>(f.x, f.y), pack2<DT>(f.z, f.w)));
   const int grp = gcol >> 7;
   // columns of this group inside the matrix: 128 (reciprocal exact) except in a last, partial group
   const float rcnt = __builtin_amdgcn_rcpf((float)min(128, N - (grp << 7)));
@@ -830,11 +830,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
                                                      int tiles_n, int nwg, unsigned long long* stamps, LnResid ln,
                                                      int stagger_unit) {
-  // row panels per group of the tile order (below): 8 for K <= 1024 (4 when the weight has more than 9 column slices),
-  // plain row-major for deeper K where one 256-row activation panel is already 1.5 MB (measured per shape with
-  // tools/bench_gemm.py --stagger 50..56: QKV +5 %, FFN-up +3 %, attention-out +2 % over row-major, FFN-down best as is)
+  // row panels per group of the tile order (below): 8 for K <= 1024, plain row-major for deeper K where one 256-row
+  // activation panel is already 1.5 MB.  What the order sets is the L2 fill volume, not the speed: the 32 workgroups of an
+  // XCD stream their K slices in step, a round of 32 tiles fetches (distinct row panels + distinct column slices) x 256 x K
+  // x 2 bytes, and NOTHING survives in the 4 MB L2 from one round to the next (a round moves 4.7 MB at K = 768) — that
+  // model reproduces FETCH_SIZE per kernel to 3-8 % (DESIGN.md "Round 3", profiles/r03_q_*).  8 row panels x 4 column
+  // slices is the cheapest rectangle of 32; the step time is the same to 0.2 % for groups of 1 / 4 / 8
+  // (profiles/r03_q_tile_order_ab.txt).
   const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50))      // A/B: 2..64
-                    : (stagger_unit == 56 || Kd > 1024) ? 1 : (tiles_n > 9 ? 4 : 8);
+                    : (stagger_unit == 56 || Kd > 1024) ? 1 : 8;
   // De-synchronise the XCDs (rr_set_tuning "gemm_desync"; stagger_unit = 100 + u).  All workgroups of a persistent launch start
   // together and every tile costs the same, so the 256 CUs run their main loops (HBM nearly idle) and then their epilogues
   // (HBM saturated) in LOCKSTEP: tools/gemm_epilogue_timeline.py shows every workgroup inside its epilogue at the same
@@ -1186,6 +1190,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     // branches and exec-mask regions per tile (3.7-3.9k cycles for ~1k cycles of arithmetic in the epilogue timeline).
     auto activate = [&](f32x4 ab) -> f32x4 {
       float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
+      if constexpr (EPI == EPI_BIAS_GELU_BF16 && RR_PK_GELU != 0) {
+        const f32x2 g0 = gelu_erf_fast2(f32x2{v0, v1}), g1 = gelu_erf_fast2(f32x2{v2, v3});
+        return f32x4{g0.x, g0.y, g1.x, g1.y};
+      }
       if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
       if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
       if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
@@ -1282,11 +1290,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           const int gm = rbase_ + (tid >> 5) + u * 16;
           const bool ok = gm < M && col_ok8;
           if constexpr ((SPLIT & 1) != 0) {
-            rh[u] = ok ? *(const uint4*)(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
-            rl[u] = ok ? *(const uint4*)(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            rh[u] = ok ? load_stream_u4(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            rl[u] = ok ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
           } else {
-            ra[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol8) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[u] = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[u] = ok ? load_stream_f4(resid + (size_t)gm * ldr + gcol8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = ok ? load_stream_f4(resid + (size_t)gm * ldr + gcol8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
       }
@@ -1383,7 +1391,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
           if (ok) {
-            *(uint4*)(ln.x16 + (size_t)gm * ln.ldx + gcol) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint4(hi[0], hi[1], hi[2], hi[3]));
             if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
               uint32_t lo[4];
 #pragma unroll
@@ -1395,11 +1403,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                   lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
                 }
               }
-              *(uint4*)(ln.lo_out + (size_t)gm * ln.ld16 + gcol) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+              store_stream(ln.lo_out + (size_t)gm * ln.ld16 + gcol, make_uint4(lo[0], lo[1], lo[2], lo[3]));
             } else {
               float* cp = (float*)Cv + (size_t)gm * ldc + gcol;
-              *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
-              *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+              store_stream(cp, make_float4(f[0], f[1], f[2], f[3]));
+              store_stream(cp + 4, make_float4(f[4], f[5], f[6], f[7]));
             }
           }
           // LayerNorm statistics of the 128-column group = the 16 lanes of this DPP row (every lane takes part)
@@ -1439,7 +1447,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             const int i = tid + (h * (UNR / 2) + u) * 512, r = i / CPR, c = i - r * CPR;
             const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
             const uint4 v = make_uint4(sw ? sv[u].z : sv[u].x, sw ? sv[u].w : sv[u].y, sw ? sv[u].x : sv[u].z, sw ? sv[u].y : sv[u].w);
-            if (gm < M && gcol < N) *(uint4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = v;
+            if (gm < M && gcol < N) store_stream((char*)Cv + ((size_t)gm * ldc + gcol) * ES, v);
           }
           RR_SBAR();
         }
@@ -1457,7 +1465,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           const int i = tid + (h * UH + u) * 512, r = i / CPR, c = i - r * CPR;
           const int gm = row_base + r, gcol = cn0 + c * (16 / ES);
           const bool ok = gm < M && gcol < N;
-          float4 x = ok ? *(const float4*)(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 x = ok ? load_stream_f4(resid + (size_t)gm * ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
           if (ln.stats) {
             const float2 st2 = *(const float2*)(lds + PARAM_OFF + 6144 + (gm - cm0) * 8);   // (rows beyond M were clamped to M - 1 by the DMA)
             x = make_float4((x.x - st2.x) * st2.y * lg.x + lb.x, (x.y - st2.x) * st2.y * lg.y + lb.y,
@@ -1474,7 +1482,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           if (ok) {
             f = *(const float4*)(stg + r * PITCH + c * 16);
             f.x += rv[u].x; f.y += rv[u].y; f.z += rv[u].z; f.w += rv[u].w;
-            *(float4*)((char*)Cv + ((size_t)gm * ldc + gcol) * ES) = f;
+            store_stream((char*)Cv + ((size_t)gm * ldc + gcol) * ES, f);
           }
           // folded LayerNorm, producer side: the 16-bit copy of the row and its statistics per 128-column group (a wave holds
           // one row of this tile per step, lane = 16-byte chunk: lanes 0-31 / 32-63 are the tile's two column groups)

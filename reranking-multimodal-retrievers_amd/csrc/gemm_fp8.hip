@@ -362,7 +362,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
             const float r_ = rs[hA][mb];
             float v0 = fmaf(acc[q][mb][4 * rg + 0], r_ * cw.x, bv.x), v1 = fmaf(acc[q][mb][4 * rg + 1], r_ * cw.y, bv.y),
                   v2 = fmaf(acc[q][mb][4 * rg + 2], r_ * cw.z, bv.z), v3 = fmaf(acc[q][mb][4 * rg + 3], r_ * cw.w, bv.w);
-            if (EPI == 1) { v0 = gelu13(v0); v1 = gelu13(v1); v2 = gelu13(v2); v3 = gelu13(v3); }
+            if constexpr (EPI == 1 && RR_PK_GELU != 0) {          // packed Horner chain (rr_common.h): same values, half the VALU issue
+              const f32x2 g0 = gelu_erf_fast2(f32x2{v0, v1}), g1 = gelu_erf_fast2(f32x2{v2, v3});
+              v0 = g0.x; v1 = g0.y; v2 = g1.x; v3 = g1.y;
+            } else if (EPI == 1) { v0 = gelu13(v0); v1 = gelu13(v1); v2 = gelu13(v2); v3 = gelu13(v3); }
             const int r = wr * 64 + mb * 32 + (lane & 31);
             // rows with bit 3 set keep the two 8-byte halves of every 16-byte chunk swapped (2-way write conflict at the
             // 528-byte pitch otherwise); the reader swaps them back — as in gemm_kernel_hp

@@ -87,6 +87,42 @@ __device__ __forceinline__ uint32_t mix_fence(const uint4& a, const uint4& b) {
   asm volatile("s_nop 1\n\tv_mov_b32 %0, 0" : "=v"(t) : "v"(a.x), "v"(b.x));
   return t;
 }
+// ---- streaming accesses of the GEMM epilogues.  An output row is written once and next read by another launch, a residual
+// row is read once: neither is worth an L2 line, and the lines they would take are the operand panels the workgroups of an
+// XCD share (RR_NT bit 0: outputs stored with the `nt` hint, bit 1: residual rows loaded with it; measured in DESIGN.md).
+#ifndef RR_NT
+#define RR_NT 1
+#endif
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_;
+__device__ __forceinline__ void store_stream(void* p, const uint4& v) {
+  if constexpr ((RR_NT & 1) != 0) __builtin_nontemporal_store(u32x4_{v.x, v.y, v.z, v.w}, (u32x4_*)p);
+  else *(uint4*)p = v;
+}
+__device__ __forceinline__ void store_stream(void* p, const uint2& v) {
+  if constexpr ((RR_NT & 1) != 0) __builtin_nontemporal_store(u32x2_{v.x, v.y}, (u32x2_*)p);
+  else *(uint2*)p = v;
+}
+__device__ __forceinline__ void store_stream(void* p, const float4& v) {
+  if constexpr ((RR_NT & 1) != 0) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (f32x4*)p);
+  else *(float4*)p = v;
+}
+__device__ __forceinline__ uint4 load_stream_u4(const void* p) {
+  if constexpr ((RR_NT & 2) != 0) {
+    const u32x4_ v = __builtin_nontemporal_load((const u32x4_*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *(const uint4*)p;
+  }
+}
+__device__ __forceinline__ float4 load_stream_f4(const void* p) {
+  if constexpr ((RR_NT & 2) != 0) {
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *(const float4*)p;
+  }
+}
 __device__ __forceinline__ uint32_t pack2rt(float lo, float hi, int dt) { return dt ? pack2<1>(lo, hi) : pack2<0>(lo, hi); }
 template <int DT>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -116,6 +152,30 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   p = fmaf(p, z, -1.151314700e+00f);
   p = fmaf(p, z, -9.999805559e-01f);
   return fmaf(-z, __builtin_amdgcn_exp2f(p), __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()));   // med3(x, 0, +inf) = max(x, 0)
+}
+
+// The same function on two values with the Horner chain as v_pk_fma_f32 (two fp32 lanes per instruction at the full VALU
+// rate: 8 packed multiply-adds for the pair instead of 16 scalar ones; |x|, min, exp2 and med3 have no packed form).
+// Every packed operand is VALU-produced (z from v_min, p from the previous packed op, coefficients from SGPR pairs), so the
+// stale-lane hazard of packed-f32 ops behind a vmcnt release (DESIGN.md "Numerics") cannot arise here; each lane's result
+// is the same IEEE fma chain as gelu_erf_fast, bit for bit.
+#ifndef RR_PK_GELU
+#define RR_PK_GELU 1
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+  const f32x2 z = {fminf(fabsf(x.x), 5.7f), fminf(fabsf(x.y), 5.7f)};
+  f32x2 p = {-1.403277905e-06f, -1.403277905e-06f};
+  p = __builtin_elementwise_fma(p, z, f32x2{5.490869060e-05f, 5.490869060e-05f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-8.929630618e-04f, -8.929630618e-04f});
+  p = __builtin_elementwise_fma(p, z, f32x2{8.417915996e-03f, 8.417915996e-03f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-5.388785911e-02f, -5.388785911e-02f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-4.584285712e-01f, -4.584285712e-01f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-1.151314700e+00f, -1.151314700e+00f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-9.999805559e-01f, -9.999805559e-01f});
+  const f32x2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+  const f32x2 m = {__builtin_amdgcn_fmed3f(x.x, 0.0f, __builtin_huge_valf()), __builtin_amdgcn_fmed3f(x.y, 0.0f, __builtin_huge_valf())};
+  return __builtin_elementwise_fma(-z, e, m);
 }
 
 // LDS byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64 x bf16] tile image

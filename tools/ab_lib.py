@@ -49,6 +49,10 @@ for r in range(int(sys.argv[2]) + 1):
 print(json.dumps({"ms": [t * 1e3 for t in ts], "sha": hashlib.sha256(out["logits"].cpu().numpy().tobytes()).hexdigest()[:16]}))
 """ % ROOT
 
+if len(sys.argv) > 1 and sys.argv[1] == "--child":       # python3 tools/ab_lib.py --child LIB INNER [KEY=INT ...]: one child in THIS process
+    sys.argv = ["-c"] + sys.argv[2:]                      # (the target of `rocprofv3 --pmc ... -- python3 tools/ab_lib.py --child ...`)
+    exec(CHILD)
+    sys.exit(0)
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
 ap.add_argument("--rounds", type=int, default=3)

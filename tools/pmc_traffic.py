@@ -26,12 +26,24 @@ def klass(name):
     return "other"
 
 
-def load(d, counter):
+def short(name):
+    """'void (anonymous namespace)::gemm_kernel_hp<1, 1, 0, 0, true>(unsigned short const*, ...' -> 'gemm_kernel_hp<1, 1, 0, 0, true>'"""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def load(d, counter, key=klass):
     tot, n = collections.Counter(), collections.Counter()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                k = klass(r["Kernel_Name"])
+                k = key(r["Kernel_Name"])
                 tot[k] += float(r["Counter_Value"])
                 n[k] += 1
     return tot, n
@@ -47,6 +59,11 @@ for k in f:
     wr = w.get(k, 0.0) * 1024.0
     out[k] = {"launches": launches, "read_bytes_per_launch": rd / launches, "write_bytes_per_launch": wr / max(1, nw.get(k, 0)),
               "hbm_bytes_per_launch": rd / launches + wr / max(1, nw.get(k, 0))}
+fk, nfk = load(fd, "FETCH_SIZE", short)
+wk, nwk = load(wd, "WRITE_SIZE", short)
+per_kernel = {k: {"launches": nfk[k], "read_gb_per_launch": round(2.0 * fk[k] * 1024.0 / nfk[k] / 1e9, 4),
+                  "write_gb_per_launch": round(wk.get(k, 0.0) * 1024.0 / max(1, nwk.get(k, 0)) / 1e9, 4)}
+              for k in sorted(fk, key=lambda k: -fk[k]) if 2.0 * fk[k] * 1024.0 > 1e8}
 print(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py (c3, 800 pairs, "
                           "1 warm-up + 1 step); FETCH_SIZE doubled per the gfx950 correction",
-                  "per_kernel_class": out}, indent=1))
+                  "per_kernel_class": out, "per_kernel": per_kernel}, indent=1))
