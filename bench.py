@@ -77,6 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--bucketed", action="store_true",
                     help="length-bucketed execution (RerankEngine.forward_ids_bucketed): with --regime realistic the pairs run at the "
                          "row length of their bucket instead of the padded seq_len; pairs/s still counts padded pairs (the contract)")
+    ap.add_argument("--packed", action="store_true",
+                    help="packed execution (RerankEngine.forward_ids_packed / rr_forward_packed): the pairs grouped by length in steps "
+                         "of --granule rows, every GEMM of a layer ONE launch over the rows that exist; pairs/s still counts padded pairs")
+    ap.add_argument("--granule", type=int, default=64, help="row-length step of --packed")
     ap.add_argument("--weights-gain", type=float, default=1.0,
                     help="std multiplier of the Linear matrices of the synthetic weights (1 = HF init: near-uniform attention; 2.5 = the "
                          "peaked-attention regime of tests/golden c3_sep).  The line then also reports how many attention workgroups "
@@ -274,11 +278,18 @@ def main():
         cls, pat = cls.to(dev), pat.to(dev)
     eng.reserve(-(-N // world) + 1, Bq, S)                   # no allocation / synchronisation inside the steps
 
+    host_lengths = None
+    if args.packed:
+        host_lengths = (((ids != 0) | (am != 0)) * torch.arange(1, S + 1, device=dev)).amax(1).clamp_(min=1).cpu().numpy()
+
     def step():
         if distributed:      # also with one rank: the same slice -> all-gather -> head path the N-GPU runs take
             return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None, want_scores=True)
         if args.bucketed:
             return eng.forward_ids_bucketed(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
+        if args.packed:        # the pair lengths are host data in the real pipeline (the tokenizer produced them)
+            return eng.forward_ids_packed(ids, am, tt, Bq, K, cls, pat, None, granule=args.granule, want_scores=True, want_order=True,
+                                          lengths=host_lengths)
         return eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
 
     def fence():
@@ -337,7 +348,9 @@ def main():
                        + f", K={K}, seq_len={S}, vision_tokens={P}",
                        "queries_per_step": Bq, "pairs_per_step": N, "token_regime": args.regime,
                        **({"execution": f"length-bucketed: {int(out['bucket_rows'])} of {N * S} padded rows computed per step"}
-                          if args.bucketed else {}),
+                          if args.bucketed else
+                          {"execution": f"packed rows (granule {args.granule}, pair lengths known on the host): {int(out['packed_rows'])} of {N * S} padded rows computed per step"}
+                          if args.packed else {}),
                        "parallelism": (f"REHEARSAL: {world} ranks time-sharing ONE GPU, logits exchanged over gloo through the host; "
                                        "not a scaling measurement") if args.rehearse_one_gpu else
                                       (f"pairs sharded over {world} GPU(s) ({nranks_seen} ranks in the process group), "

@@ -171,6 +171,26 @@ int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, in
  * fp32 summation order.  0 switches it off.  Python: RerankEngine.forward_ids_bucketed. */
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
 
+/* rr_forward_packed: the same computation over PACKED rows (SURVEY.md "Variable length"): the caller
+ * groups the pairs into n_segments segments of equal row length seg_len[i] <= padded_seq_len (the length the reference
+ * would pad to, utils.py:157-165; every pair's non-pad tokens must fit its segment's length) and hands over
+ *   input_ids / attention_mask / token_type_ids : DEVICE int64, sum_i seg_pairs[i] * seg_len[i] entries: segment after
+ *       segment, inside a segment pair after pair, seg_len[i] entries per pair (token_type_ids may be NULL);
+ *   image_cls / image_patches : DEVICE float32 PER PAIR, [n, vision_hidden] / [n, n_patches, vision_hidden] in the packed
+ *       pair order, or both NULL (a segment mixes the candidates of several queries);
+ *   logits_out (/ logits2_out for 2H_BCE) : DEVICE float32 [n] in the packed pair order; the caller scatters them back
+ *       and runs rr_head on the [Bq, K] block.
+ * Every GEMM and every LayerNorm statistics pass of a layer runs ONCE over all rows of the call; attention, the embedding
+ * gathers and the CLS heads run once per segment.  A pair's logit equals what rr_forward computes for it after
+ * rr_set_padded_seq_len(padded_seq_len) at seq_len = seg_len[i] (bit for bit), hence what the padded call computes (bit
+ * for bit for text-only models, up to fp32 summation order in the cross-encoder's attention with vision tokens).
+ * No reference counterpart (it pads); Python: RerankEngine.forward_ids_packed.  RR_ERR_BAD_SHAPE: more than 64 segments,
+ * an empty segment, a length above padded_seq_len or, with image features, below the mapping network's cross-attention
+ * window (32). */
+int rr_forward_packed(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                      const float* image_cls, const float* image_patches, int n_segments, const int32_t* seg_pairs,
+                      const int32_t* seg_len, int padded_seq_len, float* logits_out, float* logits2_out, void* hip_stream);
+
 /* rr_forward: one pass of the hot path over N = Bq*K (query,candidate) pairs.
  *   input_ids, attention_mask, token_type_ids : DEVICE int64 [N,S] row-major, query-major pair order
  *       (prepare_full_context_inputs, utils.py:129-167).  attention_mask masks keys in the text

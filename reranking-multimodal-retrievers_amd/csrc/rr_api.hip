@@ -738,10 +738,30 @@ enum OperandKind { OP_NORMALISED = 0, OP_RAW_FOLDED = 1, OP_E4M3 = 2 };   // wha
   RR_RUN(m, st, RR_K_GEMM_FP8, gemm_flops(M, N, K), 1.0 * (M) * (K) + 1.0 * (N) * (K) + 2.0 * (M) * (N) + 4.0 * (M), \
          rr_launch_gemm_fp8((const uint8_t*)(A8), lda, W8, K, bias, 1.0f, rsc, csc, C, ldc, M, N, K, epi, m->dt, st))
 
+// Packed execution (rr_forward_packed): the pairs of a call are grouped into SEGMENTS of equal row length; a segment's pairs
+// lie back to back in every activation buffer, the segments one after the other, so the row-wise kernels (every GEMM, the
+// LayerNorm statistics) run ONCE over all rows of the call while the kernels that know where a pair starts (attention, the
+// embeddings, the gathers, the CLS heads) are launched once per segment on offset pointers.  The plain forward is the
+// special case of one segment.
+struct Seg {
+  int n, S, T;             // pairs; text rows per pair; cross-encoder rows per pair (S + vision tokens)
+  size_t p0, r0, rt0;      // first pair; first text row; first cross-encoder row of the segment
+};
+struct SegView {           // what run_layer needs: rows per pair and the first row of every segment, for ONE of the two stacks
+  int n, len;
+  size_t row0;
+};
+
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
               const float* key_bias, Work& w, ResidSrc& rs, int& in_kind, bool want_h32, bool want_f32,
-              const float* dense_bias = nullptr, int dense_ld = 0) {
-  const int rows = batch * Tseq;
+              const float* dense_bias = nullptr, int dense_ld = 0, const std::vector<SegView>* segs = nullptr) {
+  int rows = batch * Tseq;
+  if (segs) {
+    if (dense_bias) return fail(m, RR_ERR_UNSUPPORTED, "internal: dense attention bias with packed segments");
+    size_t r = 0;
+    for (const SegView& g : *segs) r += (size_t)g.n * g.len;
+    rows = (int)r;
+  }
   const int nparts = (Hd + 127) / 128;
   const bool fp8 = m->cfg.fp8 && g_ln_lite && L.w1_8 && (Hd % 128 == 0);
   const bool fold = !fp8 && g_ln_fold && g_ln_lite && L.w1_f && (Hd % 8 == 0);
@@ -757,9 +777,18 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   } else {
     RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   }
-  RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
-         rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
-                             Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld));
+  if (segs) {
+    for (const SegView& g : *segs) {
+      const bf16_t* q0 = w.qkv + g.row0 * 3 * Hd;
+      RR_RUN(m, st, RR_K_ATTENTION, 4.0 * g.n * (double)g.len * g.len * Hd, 2.0 * 4.0 * g.n * g.len * Hd,
+             rr_launch_attention(q0, 3 * Hd, 1, 0, q0 + Hd, q0 + 2 * Hd, 3 * Hd, key_bias + g.row0, g.n, heads, g.len, g.len,
+                                 w.ctx + g.row0 * Hd, Hd, m->dt, st, nullptr, 0));
+    }
+  } else {
+    RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
+           rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
+                               Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld));
+  }
   if (!g_ln_lite) {   // reference dataflow for A/B runs: every LayerNorm writes the fp32 stream, residuals read it back
     RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
@@ -863,19 +892,22 @@ int ensure_adj(rr_model* m, size_t bytes, hipStream_t st) {
 
 // CLS heads + (when this call covers every pair) the scoring head.  classifier1 -> "logits", classifier2 ->
 // "logits_secondary" (utils.py:105-108); for 2H_BCE the ranked logit is the second head (rerank_model.py:589-590).
-int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K, int pair_begin, bool full,
+int run_heads(rr_model* m, hipStream_t st, Work& w, const std::vector<Seg>& segs, int Bq, int K, int pair_begin, bool full,
               const float* labels, float* logits_out, float* logits2_out, float* loss_out, float* scores_out,
               int32_t* order_out, bool logits_as_targets = false) {
   const rr_config& c = m->cfg;
   const int Hc = c.ce_hidden, N = Bq * K;
-  float* out_a = logits_out + pair_begin;
-  float* out_b = logits2_out ? logits2_out + pair_begin : w.l2;
-  if (c.loss_kind == RR_LOSS_2H_BCE) {
-    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
-           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
-  } else {
-    RR_RUN(m, st, RR_K_HEAD, 4.0 * n * Hc, 8.0 * n * Hc,
-           rr_launch_cls_heads(w.h32, T, Hc, n, m->cls1_w, m->cls1_b, m->cls2_w, m->cls2_b, out_a, out_b, st));
+  for (const Seg& g : segs) {
+    float* out_a = logits_out + pair_begin + g.p0;
+    float* out_b = (logits2_out ? logits2_out + pair_begin : w.l2) + g.p0;
+    const float* h = w.h32 + g.rt0 * Hc;
+    if (c.loss_kind == RR_LOSS_2H_BCE) {
+      RR_RUN(m, st, RR_K_HEAD, 4.0 * g.n * Hc, 8.0 * g.n * Hc,
+             rr_launch_cls_heads(h, g.T, Hc, g.n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
+    } else {
+      RR_RUN(m, st, RR_K_HEAD, 4.0 * g.n * Hc, 8.0 * g.n * Hc,
+             rr_launch_cls_heads(h, g.T, Hc, g.n, m->cls1_w, m->cls1_b, m->cls2_w, m->cls2_b, out_a, out_b, st));
+    }
   }
   if (full && (loss_out || scores_out || order_out)) {
     const int has_pw = !std::isnan(c.pos_weight);
@@ -889,21 +921,34 @@ int run_heads(rr_model* m, hipStream_t st, Work& w, int n, int T, int Bq, int K,
 
 // CrossEncoder over AttentionFusionBertModel (utils.py:85-108, attention_fusion.py:61-160): Linear(D -> Hc) ->
 // embeddings(inputs_embeds) -> Lc layers.  Input: w.li16 [n*T, D], w.ce_bias [n, T]; output: w.h32 [n*T, Hc].
-int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, int n, int T, const float* adj = nullptr, int adj_ld = 0,
-                      int s_text = -1, int vis_pos0 = 0) {
+// `segs`: one entry for the plain forward.  vis_pos0 >= 0: the vision tokens of every pair take the positions from vis_pos0 on
+// (length-bucketed / packed calls: behind the PADDED text), -1: plain positions 0 .. T-1.
+int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Seg>& segs, const float* adj = nullptr,
+                      int adj_ld = 0, int vis_pos0 = -1) {
   const rr_config& c = m->cfg;
-  const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate, RT = n * T;
+  const int D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate;
+  const Seg& last = segs.back();
+  const int RT = (int)(last.rt0 + (size_t)last.n * last.T);
+  int n = 0;
+  for (const Seg& g : segs) n += g.n;
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
-  RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * RT * Hc,
-         rr_launch_ce_embed_ln(w.pre, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, RT, T, Hc, w.h32, w.h16, m->dt, st,
-                               s_text, vis_pos0));
+  std::vector<SegView> view;
+  for (const Seg& g : segs) {
+    RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * g.n * g.T * Hc,
+           rr_launch_ce_embed_ln(w.pre + g.rt0 * Hc, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, g.n * g.T, g.T, Hc,
+                                 w.h32 + g.rt0 * Hc, w.h16 + g.rt0 * Hc, m->dt, st, vis_pos0 >= 0 ? g.S : -1,
+                                 vis_pos0 >= 0 ? vis_pos0 : 0));
+    view.push_back(SegView{g.n, g.T, g.rt0});
+  }
+  const bool packed = segs.size() > 1;
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
     int folded = OP_NORMALISED;
     for (int l = 0; l < c.ce_layers; ++l)
-      RR_TRY(run_layer(m, st, m->ce_layers[l], n, T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
+      RR_TRY(run_layer(m, st, m->ce_layers[l], n, last.T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
                        l == c.ce_layers - 1, true,          // the CLS heads read the fp32 rows of the last layer
-                       adj, adj_ld));                       // attention fusion: the same bias in every layer
+                       adj, adj_ld,                         // attention fusion: the same bias in every layer
+                       packed ? &view : nullptr));
   }
   m->tap_ce = w.h32;
   m->tap_ce_elems = (size_t)RT * Hc;
@@ -1261,7 +1306,9 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
                         int S, const float* labels, int pair_begin, int pair_end, float* logits_out,
                         float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream,
                         int joint, int q_len, long long instruction_token, const float* preflmr_scores = nullptr,
-                        float fusion_multiplier = 1.0f) {
+                        float fusion_multiplier = 1.0f, const std::vector<std::pair<int, int>>* packed = nullptr) {
+  // `packed` (rr_forward_packed): segments (pairs, rows per pair); the token arrays then hold the segments' pairs back to back
+  // at THEIR row length, Bq = number of pairs, K = 1 (image features per pair), S = the padded length the reference would use
   if (!h) return RR_ERR_BAD_ARG;
   rr_model* m = h;
   const rr_config& c = m->cfg;
@@ -1281,13 +1328,16 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     return fail(m, RR_ERR_BAD_SHAPE, "cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", T, c.ce_max_pos);
   // length-bucketed forward (rr_set_padded_seq_len): S is this call's (shorter) row length, the cross-encoder positions of the
   // vision tokens are those behind the padded text
-  int s_text = -1, vis_pos0 = 0;
-  if (m->padded_S > 0 && !joint && S != m->padded_S) {
+  int vis_pos0 = -1;
+  if (m->padded_S > 0 && !joint && !packed && S != m->padded_S) {
     if (S > m->padded_S) return fail(m, RR_ERR_BAD_SHAPE, "seq_len %d exceeds the padded length %d set by rr_set_padded_seq_len", S, m->padded_S);
     if (m->padded_S + P > c.ce_max_pos)
       return fail(m, RR_ERR_BAD_SHAPE, "padded cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", m->padded_S + P, c.ce_max_pos);
-    s_text = S;
     vis_pos0 = m->padded_S;
+  }
+  if (packed) {
+    if (joint || K != 1) return fail(m, RR_ERR_BAD_ARG, "internal: packed forward is per pair and not joint");
+    vis_pos0 = S;
   }
   const bool full = pair_begin == 0 && pair_end == N;
   if (c.loss_kind == RR_LOSS_NEGATIVE_SAMPLING && labels)
@@ -1315,10 +1365,28 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   m->last_stream = st;
 
   const int Hd = c.hidden, I = c.intermediate, D = c.li_dim, Hc = c.ce_hidden, Ic = c.ce_intermediate;
-  const int R = n * S, RT = n * T;
+  (void)Hc; (void)Ic;
   const int64_t* ids = input_ids + (size_t)pair_begin * S;
   const int64_t* am = attention_mask + (size_t)pair_begin * S;
   const int64_t* tts = token_type_ids ? token_type_ids + (size_t)pair_begin * S : nullptr;
+  // segments: one (n pairs of S rows) for the plain forward
+  std::vector<Seg> segs;
+  std::vector<SegView> text_view;
+  if (packed) {
+    size_t p0 = 0, r0 = 0, rt0 = 0;
+    for (const auto& g : *packed) {
+      segs.push_back(Seg{g.first, g.second, g.second + P, p0, r0, rt0});
+      p0 += (size_t)g.first;
+      r0 += (size_t)g.first * g.second;
+      rt0 += (size_t)g.first * (g.second + P);
+    }
+    for (const Seg& g : segs) text_view.push_back(SegView{g.n, g.S, g.r0});
+  } else {
+    segs.push_back(Seg{n, S, T, 0, 0, 0});
+  }
+  const int R = (int)(segs.back().r0 + (size_t)segs.back().n * segs.back().S);       // text rows of the call
+  const int RT = (int)(segs.back().rt0 + (size_t)segs.back().n * segs.back().T);     // cross-encoder rows
+  const std::vector<SegView>* tv = packed ? &text_view : nullptr;
 
   // ---- masks -> additive key bias (text: tokenizer mask; cross encoder: id != 0, vision = 1)
   const int txt_split = joint ? q_len : (1 << 30), txt_shift = joint ? P : 0;   // [query | image | context] reorder
@@ -1327,18 +1395,21 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     RR_RUN(m, st, RR_K_EMBED, 0.0, 24.0 * R + 4.0 * RT,
            rr_launch_joint_masks(ids, am, n, S, P, q_len, instruction_token, w.text_bias, w.li_mask, w.ce_bias, st));
   } else {
-    RR_RUN(m, st, RR_K_EMBED, 0.0, 16.0 * R + 8.0 * RT, rr_launch_key_bias(ids, am, n, S, T, w.text_bias, w.ce_bias, st));
+    for (const Seg& g : segs)
+      RR_RUN(m, st, RR_K_EMBED, 0.0, 16.0 * g.n * g.S + 8.0 * g.n * g.T,
+             rr_launch_key_bias(ids + g.r0, am + g.r0, g.n, g.S, g.T, w.text_bias + g.r0, w.ce_bias + g.rt0, st));
   }
   // ---- text encoder (FLMRTextModel = BertModel)
-  RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * R * Hd,
-         rr_launch_embed_ln(ids, tts, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps, R, S, Hd, c.vocab_size,
-                            c.type_vocab, w.h32, w.h16, m->dt, st));
+  for (const Seg& g : segs)
+    RR_RUN(m, st, RR_K_EMBED, 0.0, (3 * 4.0 + 6.0) * g.n * g.S * Hd,
+           rr_launch_embed_ln(ids + g.r0, tts ? tts + g.r0 : nullptr, m->word, m->pos, m->type, m->emb_g, m->emb_b, c.ln_eps,
+                              g.n * g.S, g.S, Hd, c.vocab_size, c.type_vocab, w.h32 + g.r0 * Hd, w.h16 + g.r0 * Hd, m->dt, st));
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
     int folded = OP_NORMALISED;
     for (int l = 0; l < c.layers; ++l)                    // the last layer's normalised rows feed the 768 -> 128 projection
       RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs, folded,
-                       l == c.layers - 1, m->debug));
+                       l == c.layers - 1, m->debug, nullptr, 0, tv));
   }
   if (m->debug) {
     const size_t el = (size_t)R * Hd;
@@ -1351,9 +1422,10 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   }
   // ---- 768 -> 128 projection (no bias), mask, L2 normalise -> li16[:, :S]
   RR_GEMM(m, st, w.h16, Hd, m->w_li, nullptr, nullptr, 0, w.li32, D, R, D, Hd, EPI_BIAS_F32, 4.0);
-  RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * R * D + 8.0 * R,
-         rr_launch_li_normalize(w.li32, ids, S, n, S, D, T, 0, 0, 1, 0, w.li16, m->dt, 1, joint ? w.li_mask : nullptr,
-                                txt_split, txt_shift, st));
+  for (const Seg& g : segs)
+    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * g.n * g.S * D + 8.0 * g.n * g.S,
+           rr_launch_li_normalize(w.li32 + g.r0 * D, ids + g.r0, g.S, g.n, g.S, D, g.T, 0, 0, 1, 0, w.li16 + g.rt0 * D, m->dt, 1,
+                                  joint ? w.li_mask : nullptr, txt_split, txt_shift, st));
 
   if (vision) {
     const int np = c.n_patches, PL = c.prefix_len, Vh = c.vision_hidden, mid = D * PL / 2, outd = D * PL;
@@ -1363,17 +1435,22 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * Vh, rr_launch_f32_to_bf16(cls, w.cls16, (size_t)nq * Vh, m->dt, st));
     RR_GEMM(m, st, w.cls16, Vh, m->w_vp0, m->b_vp0, nullptr, 0, w.vp_mid16, mid, nq, mid, Vh, EPI_BIAS_TANH_BF16, 2.0);
     RR_GEMM(m, st, w.vp_mid16, mid, m->w_vp2, m->b_vp2, nullptr, 0, w.vp_out32, outd, nq, outd, mid, EPI_BIAS_F32, 4.0);
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * PL * D,
-           rr_launch_li_normalize(w.vp_out32, nullptr, 0, n, PL, D, T, vis_off, pair_begin, K, q_lo, w.li16, m->dt, 1,
-                                  nullptr, 1 << 30, 0, st));
+    for (const Seg& g : segs)           // (packed: per pair, K = 1 -> pair p0 + i reads prefix p0 + i)
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * g.n * PL * D,
+             rr_launch_li_normalize(w.vp_out32, nullptr, 0, g.n, PL, D, g.T, packed ? g.S : vis_off, pair_begin + (int)g.p0, K,
+                                    q_lo, w.li16 + g.rt0 * D, m->dt, 1, nullptr, 1 << 30, 0, st));
     // mapping network: input linear + self-attention block depend on the image only => per query
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Vh, rr_launch_f32_to_bf16(pat, w.pat16, (size_t)nq * np * Vh, m->dt, st));
     RR_GEMM(m, st, w.pat16, Vh, m->w_min, m->b_min, nullptr, 0, w.t32, Hd, nq * np, Hd, Vh, EPI_BIAS_F32, 4.0);
     RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * nq * np * Hd, rr_launch_f32_to_bf16(w.t32, w.t16, (size_t)nq * np * Hd, m->dt, st));
-    const int ca = S < c.cross_attn_len ? S : c.cross_attn_len;
+    int ca = S < c.cross_attn_len ? S : c.cross_attn_len;
+    for (const Seg& g : segs) ca = g.S < ca ? g.S : ca;
+    if (packed && ca != (S < c.cross_attn_len ? S : c.cross_attn_len))
+      return fail(m, RR_ERR_BAD_SHAPE, "packed segment shorter than the %d rows the mapping network's cross-attention reads", c.cross_attn_len);
     // pair-specific text states the cross-attention reads: first `ca` rows of every pair (rerank_model.py:438-442)
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * n * ca * Hd,
-           rr_launch_gather_rows(w.h16, w.enc16, n, ca, S, Hd * 2, 0, 1, 0, st));
+    for (const Seg& g : segs)
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 4.0 * g.n * ca * Hd,
+             rr_launch_gather_rows(w.h16 + g.r0 * Hd, w.enc16 + g.p0 * ca * Hd, g.n, ca, g.S, Hd * 2, 0, 1, 0, st));
     const float* tin32 = w.t32;    // [nq*np, Hd] (per query) for layer 0; per pair afterwards
     const bf16_t* tin16 = w.t16;
     for (int l = 0; l < c.map_layers; ++l) {
@@ -1415,9 +1492,10 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
              rr_launch_gather_rows(w.t16, w.m16, n, np, np, Hd * 2, pair_begin, K, q_lo, st));
     }
     RR_GEMM(m, st, w.m16, Hd, m->w_mout, m->b_mout, nullptr, 0, w.mo32, D, n * np, D, Hd, EPI_BIAS_F32, 4.0);
-    RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * n * np * D,
-           rr_launch_li_normalize(w.mo32, nullptr, 0, n, np, D, T, vis_off + PL, 0, 1, 0, w.li16, m->dt, 1, nullptr, 1 << 30,
-                                  0, st));
+    for (const Seg& g : segs)
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 6.0 * g.n * np * D,
+             rr_launch_li_normalize(w.mo32 + g.p0 * np * D, nullptr, 0, g.n, np, D, g.T, (packed ? g.S : vis_off) + PL, 0, 1, 0,
+                                    w.li16 + g.rt0 * D, m->dt, 1, nullptr, 1 << 30, 0, st));
   }
   m->tap_li = w.li16;
   m->tap_li_elems = (size_t)RT * D;
@@ -1433,8 +1511,8 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
            rr_launch_fusion_adj(preflmr_scores, S, q_len + P, S - q_len, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st));
     adj = m->adj;
   }
-  RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld, s_text, vis_pos0));
-  return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
+  RR_TRY(run_cross_encoder(m, st, w, segs, adj, adj_ld, vis_pos0));
+  return run_heads(m, st, w, segs, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
                    loss_out, scores_out, order_out, joint != 0);
 }
 
@@ -1445,6 +1523,32 @@ static int rr_forward_impl(rr_handle h, const int64_t* input_ids, const int64_t*
   return forward_full(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, Bq, K, S, labels,
                       pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream, 0, 0,
                       -1);
+}
+
+// Packed (variable-length) FullContextRerankModel forward: see include/rerank_mi355.h.
+static int rr_forward_packed_impl(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
+                                  const float* image_cls, const float* image_patches, int n_segments, const int32_t* seg_pairs,
+                                  const int32_t* seg_len, int padded_seq_len, float* logits_out, float* logits2_out,
+                                  void* hip_stream) {
+  if (!h) return RR_ERR_BAD_ARG;
+  rr_model* m = h;
+  if (!seg_pairs || !seg_len) return fail(m, RR_ERR_BAD_ARG, "rr_forward_packed: null segment tables");
+  if (n_segments <= 0 || n_segments > 64) return fail(m, RR_ERR_BAD_SHAPE, "rr_forward_packed: %d segments (1..64)", n_segments);
+  std::vector<std::pair<int, int>> segs;
+  long long pairs = 0, rows = 0;
+  const int P = (image_cls || image_patches) ? m->cfg.prefix_len + m->cfg.n_patches : 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (seg_pairs[i] <= 0 || seg_len[i] <= 0 || seg_len[i] > padded_seq_len)
+      return fail(m, RR_ERR_BAD_SHAPE, "rr_forward_packed: segment %d holds %d pairs of %d rows (padded length %d)", i, seg_pairs[i],
+                  seg_len[i], padded_seq_len);
+    segs.emplace_back(seg_pairs[i], seg_len[i]);
+    pairs += seg_pairs[i];
+    rows += (long long)seg_pairs[i] * (seg_len[i] + P);
+  }
+  if (pairs > (1 << 24) || rows > (1LL << 30)) return fail(m, RR_ERR_BAD_SHAPE, "rr_forward_packed: %lld pairs / %lld rows", pairs, rows);
+  const int n = (int)pairs;
+  return forward_full(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, n, 1, padded_seq_len, nullptr, 0, n,
+                      logits_out, logits2_out, nullptr, nullptr, nullptr, hip_stream, 0, 0, -1, nullptr, 1.0f, &segs);
 }
 
 static int rr_forward_joint_impl(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask,
@@ -1530,8 +1634,9 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
              rr_launch_fusion_adj(preflmr_scores, Lc, Lq, Lc, fusion_multiplier, pair_begin, n, m->adj, adj_ld, st, 0));
       adj = m->adj;
     }
-    RR_TRY(run_cross_encoder(m, st, w, n, T, adj, adj_ld));
-    return run_heads(m, st, w, n, T, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+    const std::vector<Seg> one{Seg{n, T, T, 0, 0, 0}};
+    RR_TRY(run_cross_encoder(m, st, w, one, adj, adj_ld));
+    return run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
                      order_out);
   }
   if (preflmr_scores) return fail(m, RR_ERR_UNSUPPORTED, "Attention adj is not implemented for MORES");   // mores_model.py:72-73
@@ -1573,7 +1678,8 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
   }
   m->tap_ce = w.h32;
   m->tap_ce_elems = (size_t)n * Lq * Hc;
-  return run_heads(m, st, w, n, Lq, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+  const std::vector<Seg> one{Seg{n, Lq, Lq, 0, 0, 0}};
+  return run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
                    order_out);
 }
 
@@ -1827,6 +1933,9 @@ int rr_head(rr_handle h, const float* logits, const float* logits2, const float*
 }
 int rr_forward(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int Bq, int K, int S, const float* labels, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_forward_impl(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, Bq, K, S, labels, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });
+}
+int rr_forward_packed(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int n_segments, const int32_t* seg_pairs, const int32_t* seg_len, int padded_seq_len, float* logits_out, float* logits2_out, void* hip_stream) {
+  return guarded(h, [&]() -> int { return rr_forward_packed_impl(h, input_ids, attention_mask, token_type_ids, image_cls, image_patches, n_segments, seg_pairs, seg_len, padded_seq_len, logits_out, logits2_out, hip_stream); });
 }
 int rr_forward_joint(rr_handle h, const int64_t* joint_input_ids, const int64_t* joint_attention_mask, const float* image_cls, const float* image_patches, int Bq, int K, int S, int query_len, int64_t instruction_token_id, int pair_begin, int pair_end, float* logits_out, float* logits2_out, float* loss_out, float* scores_out, int32_t* order_out, void* hip_stream) {
   return guarded(h, [&]() -> int { return rr_forward_joint_impl(h, joint_input_ids, joint_attention_mask, image_cls, image_patches, Bq, K, S, query_len, instruction_token_id, pair_begin, pair_end, logits_out, logits2_out, loss_out, scores_out, order_out, hip_stream); });

@@ -356,6 +356,74 @@ class RerankEngine:
         out["bucket_rows"] = sum(n * sizes[b] for b, n in enumerate(counts))      # rows actually computed (N * S when nothing fits a bucket)
         return out
 
+    def forward_ids_packed(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, token_type_ids: Optional[torch.Tensor],
+                           Bq: int, K: int, image_cls: Optional[torch.Tensor] = None,
+                           image_patches: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                           granule: int = 64, want_scores: bool = False, want_order: bool = False,
+                           lengths: Optional[Sequence[int]] = None):
+        """The same result as `forward_ids` on right-padded pairs, computed over PACKED rows (rr_forward_packed): the pairs are
+        grouped by their length rounded up to a multiple of `granule` and laid out group after group, so that every GEMM /
+        LayerNorm pass of a layer runs once over the rows that exist — the reference pads every pair to
+        max_decoder_source_length (utils.py:157-165) — while attention runs once per group.  Against forward_ids_bucketed
+        (one whole forward per group): the same rows at granule 128, but one large GEMM launch instead of one per group,
+        which is what lets the granule shrink to 64.  Logits: bit-identical to forward_ids_bucketed on the same groups, i.e.
+        to forward_ids for text-only models.  `lengths`: the pairs' token counts (1 + index of the last non-pad position) as
+        the HOST knows them from the tokenizer (pair_inputs.prepare_full_context_inputs keeps them); without it they are
+        derived on the device and the group counts cost one device -> host copy per call, which drains the stream between
+        two forwards.  Returns the dict of forward_ids plus `packed_rows`."""
+        dev = self.device
+        N, S = input_ids.shape
+        assert N == Bq * K and granule > 0
+        floor = int(self.arch.get("cross_attn_len", 32)) if image_cls is not None else 1   # the mapping network's cross-attention window
+        sizes = sorted({min(S, max(floor, g)) for g in range(granule, S + granule, granule)})
+        if lengths is not None:
+            import numpy as np
+            ln = np.clip(np.asarray(lengths, dtype=np.int64).reshape(-1), 1, S)
+            assert ln.shape[0] == N, "one length per pair"
+            which_h = np.searchsorted(np.asarray(sizes), ln, side="left")      # smallest group length >= len
+            counts = np.bincount(which_h, minlength=len(sizes)).tolist()
+            order = torch.from_numpy(np.argsort(which_h, kind="stable")).to(dev, non_blocking=True)
+        else:
+            cols = torch.arange(1, S + 1, device=dev)
+            used = (input_ids != 0) | (attention_mask != 0)
+            lens = (used * cols).amax(1).clamp_(min=1)                     # 1 + index of the last non-pad position
+            which = torch.bucketize(lens, torch.tensor(sizes, device=dev))  # smallest group length >= len
+            counts = torch.bincount(which, minlength=len(sizes)).cpu().tolist()
+            order = torch.argsort(which, stable=True)
+        parts = [[], [], []]
+        seg_n, seg_len, o = [], [], 0
+        for b, n in enumerate(counts):
+            if n == 0:
+                continue
+            idx = order[o: o + n]
+            o += n
+            for dst, t in zip(parts, (input_ids, attention_mask, token_type_ids)):
+                if t is not None:
+                    dst.append(t.index_select(0, idx)[:, :sizes[b]].reshape(-1))
+            seg_n.append(n)
+            seg_len.append(sizes[b])
+        ids_p, am_p = torch.cat(parts[0]), torch.cat(parts[1])
+        tt_p = torch.cat(parts[2]) if token_type_ids is not None else None
+        cls_p = pat_p = None
+        if image_cls is not None:                                       # per pair: a group mixes candidates of several queries
+            q = torch.div(order, K, rounding_mode="floor")
+            cls_p = image_cls.index_select(0, q).float().contiguous()
+            pat_p = image_patches.index_select(0, q).float().contiguous()
+        two = self.arch["loss_fn"] == "2H_BCE"
+        lp = torch.empty(N, dtype=torch.float32, device=dev)
+        lp2 = torch.empty(N, dtype=torch.float32, device=dev) if two else None
+        sn = (C.c_int32 * len(seg_n))(*seg_n)
+        sl = (C.c_int32 * len(seg_n))(*seg_len)
+        L.check(self.lib.rr_forward_packed(self.h, L.ptr(ids_p), L.ptr(am_p), L.ptr(tt_p), L.ptr(cls_p), L.ptr(pat_p), len(seg_n),
+                                           sn, sl, S, L.ptr(lp), L.ptr(lp2), torch.cuda.current_stream(dev).cuda_stream),
+                self.h, "rr_forward_packed")
+        logits = torch.empty_like(lp).index_copy_(0, order, lp)
+        logits2 = torch.empty_like(lp).index_copy_(0, order, lp2) if two else torch.empty(N, dtype=torch.float32, device=dev)
+        out = self.head(logits, logits2 if two else None, labels, Bq, K, want_scores=want_scores, want_order=want_order)
+        out["logits"], out["logits2"] = logits, logits2
+        out["packed_rows"] = sum(n * s for n, s in zip(seg_n, seg_len))
+        return out
+
     def encode_image(self, pixel_values: torch.Tensor):
         """CLIP vision tower (rr_encode_image): pixel_values [B,3,IS,IS] -> (last_hidden_state[:,0] [B,Vh],
         hidden_states[-2][:,1:] [B,np,Vh]) — what rerank_model.py:408-411,424-426 takes from context_vision_encoder."""

@@ -527,6 +527,74 @@ def test_length_bucketed_forward_equals_the_padded_forward(name):
     assert torch.equal(again["logits"], ref["logits"])
 
 
+@pytest.mark.parametrize("name", ["c2", "tiny_mm"])
+def test_packed_forward_equals_the_bucketed_and_the_padded_forward(name):
+    """RerankEngine.forward_ids_packed (rr_forward_packed): the pairs laid out group after group at their group's row length,
+    every GEMM of a layer ONE launch over all rows, attention / embeddings / CLS heads per group.  Must equal the bucketed
+    forward on the same groups bit for bit (the same kernels on the same rows, only the launch boundaries move), hence the
+    padded forward bit for bit for a text-only model and up to fp32 summation order with vision tokens."""
+    g = load_golden(name)
+    cfg, vision = g["cfg"], g["vision"]
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    eng = _engine(cfg, vision, w, "fp16")
+    Bq, K, S = 3, 7, g["S"]
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=31, regime="realistic")
+    img = O.make_image_feats(cfg, Bq, seed=31) if vision else (None, None)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K, None if img[0] is None else img[0].cuda(), None if img[1] is None else img[1].cuda())
+    ref = eng.forward_ids(*args, None, want_order=True)
+    gran = S // 4
+    sizes = sorted({min(S, max(int(eng.arch.get("cross_attn_len", 32)) if vision else 1, s_)) for s_ in range(gran, S + gran, gran)})
+    bucketed = eng.forward_ids_bucketed(*args, None, buckets=tuple(sizes[:-1]), want_order=True)
+    got = eng.forward_ids_packed(*args, None, granule=gran, want_order=True)
+    torch.cuda.synchronize()
+    assert got["packed_rows"] == bucketed["bucket_rows"] < Bq * K * S
+    if vision:      # the per-pair vision GEMMs run over other row counts (other tile shapes): equal up to fp32 summation order
+        assert (got["logits"] - bucketed["logits"]).abs().max().item() < 5e-5
+        assert (got["logits"] - ref["logits"]).abs().max().item() < 5e-5
+    else:
+        assert torch.equal(got["logits"], bucketed["logits"])
+        assert torch.equal(got["order"], bucketed["order"])
+        assert torch.equal(got["logits"], ref["logits"])
+    assert abs(got["loss"].item() - ref["loss"].item()) < 1e-5
+    # host-side lengths (what the tokenizer knows) give the same groups as the device-side derivation
+    host = eng.forward_ids_packed(*args, None, granule=gran, want_order=True, lengths=((ids != 0) | (am != 0)).long().mul(torch.arange(1, S + 1)).amax(1).tolist())
+    torch.cuda.synchronize()
+    assert torch.equal(host["logits"], got["logits"]) and host["packed_rows"] == got["packed_rows"]
+    # one group only (granule = S) is the plain forward; and the handle is unchanged afterwards
+    one = eng.forward_ids_packed(*args, None, granule=S, want_order=True)
+    again = eng.forward_ids(*args, None, want_order=True)
+    torch.cuda.synchronize()
+    assert torch.equal(again["logits"], ref["logits"])
+    assert (one["logits"] - ref["logits"]).abs().max().item() < 5e-5 if vision else torch.equal(one["logits"], ref["logits"])
+
+
+def test_packed_forward_refuses_bad_segment_tables():
+    """rr_forward_packed argument checks: status codes, no launch (include/rerank_mi355.h)."""
+    import ctypes as C
+    from rmr_amd import _lib
+    g = load_golden("c2")
+    cfg = g["cfg"]
+    eng = _engine(cfg, False, O.make_weights(cfg, seed=0, vision=False), "fp16")
+    S = g["S"]
+    ids = torch.ones(4 * S, dtype=torch.int64, device="cuda")
+    out = torch.empty(4, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(ns, lens, nseg=None):
+        sn, sl = (C.c_int32 * len(ns))(*ns), (C.c_int32 * len(lens))(*lens)
+        return eng.lib.rr_forward_packed(eng.h, ids.data_ptr(), ids.data_ptr(), None, None, None, len(ns) if nseg is None else nseg,
+                                         sn, sl, S, out.data_ptr(), None, st)
+    assert call([4], [S]) == 0
+    assert call([4], [S + 1]) == _lib.RR_ERR_BAD_SHAPE                     # longer than the padded length
+    assert call([0], [S]) == _lib.RR_ERR_BAD_SHAPE                         # empty segment
+    assert call([2, 2], [S // 2, 0]) == _lib.RR_ERR_BAD_SHAPE
+    assert call([4], [S], nseg=0) == _lib.RR_ERR_BAD_SHAPE
+    assert call([4], [S], nseg=65) == _lib.RR_ERR_BAD_SHAPE
+    assert eng.lib.rr_forward_packed(eng.h, ids.data_ptr(), ids.data_ptr(), None, None, None, 1, None, None, S, out.data_ptr(), None,
+                                     st) == _lib.RR_ERR_BAD_ARG
+    torch.cuda.synchronize()
+
+
 def test_lightning_checkpoint_keys_load_through_the_prefix():
     """Reranker_base_executor.py:351-381 loads `checkpoint['state_dict']` with strict=False: keys carry the executor's
     `reranker.` prefix, tensors may be bf16/fp16 (mixed-precision checkpoints), and unrelated entries (optimizer/metric
