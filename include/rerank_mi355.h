@@ -171,6 +171,15 @@ int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, in
  * fp32 summation order.  0 switches it off.  Python: RerankEngine.forward_ids_bucketed. */
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
 
+/* Range guard of the 16-bit residual rows.  With the folded LayerNorm the RAW pre-LayerNorm rows are MFMA operands and the
+ * `hi` half of the residual stream; fp16 (the mode that meets 1e-3) ends at 65 504.  The kernel that merges the rows'
+ * LayerNorm statistics raises a device-side flag when a row's sum of squares reaches 9e8 (no element of a row below that can
+ * exceed 3e4) or is not finite; BERT-family activations stay four orders of magnitude below.  rr_activation_range_flag
+ * copies the flag to *flag_out (synchronises `hip_stream`; call it outside the hot loop, e.g. once per evaluation batch
+ * group) and clears it when reset != 0.  A raised flag means: rebuild the handle with compute_dtype = 0 (bf16, the
+ * reference's autocast type, same exponent range as fp32).  Python: RerankEngine.activation_range_exceeded(). */
+int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_stream);
+
 /* rr_forward_packed: the same computation over PACKED rows (SURVEY.md "Variable length"): the caller
  * groups the pairs into n_segments segments of equal row length seg_len[i] <= padded_seq_len (the length the reference
  * would pad to, utils.py:157-165; every pair's non-pad tokens must fit its segment's length) and hands over

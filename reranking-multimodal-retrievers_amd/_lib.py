@@ -60,6 +60,7 @@ _SIGS = {
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
     "rr_set_padded_seq_len": (C.c_int, [_P, C.c_int]),
     "rr_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "rr_activation_range_flag": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P]),
     "rr_forward_packed": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
     "rr_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                              _P, _P, _P, _P, _P, _P]),

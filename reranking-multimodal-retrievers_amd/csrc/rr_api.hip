@@ -178,6 +178,7 @@ struct rr_model {
   // workspace (grow-only)
   char* ws = nullptr;
   size_t ws_cap = 0;
+  int* range_flag = nullptr;           // device word raised by ln_finalize when a residual row nears the fp16 range (rr_activation_range_flag)
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
   bool pinned_blocks = false;          // rr_reserve was called or a stream capture was seen: outgrown blocks are retired, not freed
   std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
@@ -842,7 +843,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     if (split) f1.lo_out = lo16;
     RR_GEMM_LN_PREP(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, f1);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
-           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st));
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st, m->range_flag));
     GemmFold fi;
     fi.in_stats = w.stats_a;
     fi.csum = L.c1_f;
@@ -855,7 +856,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     if (split_out) f2.lo_out = lo16;
     RR_GEMM_LN_PREP(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, f2);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
-           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st));
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st, m->range_flag));
     rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
     if (split_out) { rs.x = nullptr; rs.hi = w.h16; rs.lo = lo16; }
     in_kind = OP_RAW_FOLDED;
@@ -1122,6 +1123,10 @@ static int rr_finalize_weights_impl(rr_handle h) {
     if (!h->host.count(n)) return fail(h, RR_ERR_MISSING_WEIGHT, "missing weight: %s", n.c_str());
   rr_model* m = h;
   const rr_config& c = m->cfg;
+  if (!m->range_flag) {
+    RR_TRY(dev_alloc(m, (void**)&m->range_flag, sizeof(int)));
+    RR_HIP(m, hipMemset(m->range_flag, 0, sizeof(int)));
+  }
   RR_HIP(m, hipSetDevice(c.device));
   if (c.model_kind != RR_MODEL_FULL_CONTEXT) {
     RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
@@ -2007,6 +2012,20 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host) {
   if (!w_host || !out_host || !scales_host || rows <= 0 || cols <= 0) return RR_ERR_BAD_ARG;
   return guarded(nullptr, [&]() -> int { host_quantize_rows(w_host, (size_t)rows, (size_t)cols, out_host, scales_host); return RR_OK; });
+}
+int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_stream) {
+  if (!h || !flag_out) return RR_ERR_BAD_ARG;
+  return guarded(h, [&]() -> int {
+    rr_model* m = h;
+    *flag_out = 0;
+    if (!m->range_flag) return RR_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RR_HIP(m, hipSetDevice(m->cfg.device));
+    RR_HIP(m, hipMemcpyAsync(flag_out, m->range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (reset) RR_HIP(m, hipMemsetAsync(m->range_flag, 0, sizeof(int), st));
+    RR_HIP(m, hipStreamSynchronize(st));
+    return RR_OK;
+  });
 }
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len) {
   if (!h || padded_seq_len < 0) return RR_ERR_BAD_ARG;

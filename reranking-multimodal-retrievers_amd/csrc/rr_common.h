@@ -293,7 +293,8 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
                                const GemmFold& fold, void* C, int ldc, int M, int N, int Kd, int epilogue, int dt,
                                hipStream_t st);
 // (mean, sum of squared deviations) per 128-column group -> (mean, rstd) per row (Chan's pairwise merge, fp32)
-hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st);
+hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st,
+                                 int* range_flag = nullptr);
 
 // fp8 (csrc/gemm_fp8.hip, elementwise.hip)
 hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* bias, float scale,

@@ -424,6 +424,15 @@ class RerankEngine:
         out["packed_rows"] = sum(n * s for n, s in zip(seg_n, seg_len))
         return out
 
+    def activation_range_exceeded(self, reset: bool = True) -> bool:
+        """True when, since the last reset, a pre-LayerNorm residual row came within a factor 2 of the fp16 range (or was
+        not finite) — rr_activation_range_flag; synchronises the current stream, so call it once per batch group, not per
+        forward.  The remedy is an engine with compute_dtype="bf16" (DESIGN.md "Numerics")."""
+        flag = C.c_int(0)
+        L.check(self.lib.rr_activation_range_flag(self.h, int(reset), C.byref(flag), torch.cuda.current_stream(self.device).cuda_stream),
+                self.h, "rr_activation_range_flag")
+        return flag.value != 0
+
     def encode_image(self, pixel_values: torch.Tensor):
         """CLIP vision tower (rr_encode_image): pixel_values [B,3,IS,IS] -> (last_hidden_state[:,0] [B,Vh],
         hidden_states[-2][:,1:] [B,np,Vh]) — what rerank_model.py:408-411,424-426 takes from context_vision_encoder."""
