@@ -364,6 +364,18 @@ int rr_op_gemm_fp8(const uint8_t* A8, const uint8_t* W8, const float* bias, floa
  * persistent ring on v_mfma_scale_f32_32x32x64_f8f6f4, small ones the two-stage kernel. */
 int rr_op_gemm_fp8_rc(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
                       int M, int N, int K, int epilogue, void* out, void* hip_stream);
+/* The two GEMMs of the fp8 configuration's FFN on the persistent e4m3 ring (shapes with at least 512 tiles of 256 x 256,
+ * K % 128 == 0, N % 16 == 0; RR_ERR_BAD_SHAPE otherwise):
+ *   rr_op_gemm_fp8_gelu_e4m3: out8[M,N] = e4m3(clamp(out_mul * gelu(row_scale[m] * col_scale[n] * (A8 . W8^T) + bias), +-448)):
+ *     the GELU output under ONE static scale (the forward uses 8), the A operand of
+ *   rr_op_gemm_fp8_resid: out[M,N] (f32) = scale * col_scale[n] * (A8 . W8^T) + bias + r, r = resid[M,N] when stats == NULL,
+ *     else gamma * (resid - mean_m) * rstd_m + beta with stats[m] = (mean, rstd) — the fp32-stream residual epilogue of
+ *     rr_op_gemm_ln_resid_f32 behind an e4m3 GEMM.  Reference seam: BertIntermediate / BertOutput of stock HF BERT. */
+int rr_op_gemm_fp8_gelu_e4m3(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
+                             float out_mul, int M, int N, int K, uint8_t* out8, void* hip_stream);
+int rr_op_gemm_fp8_resid(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, const float* col_scale,
+                         const float* resid, const float* stats, const float* gamma, const float* beta, int M, int N, int K, float* out,
+                         void* hip_stream);
 /* Per-tensor e4m3 quantisation for rr_op_gemm_fp8: out[i] = e4m3(clamp(x[i] / scale, +-448)), round to nearest even;
  * x holds n (a multiple of 8) f32 values (x_is_f32 != 0) or bf16 values.  rr_op_amax: *out_dev (device float) = max |x|
  * (exact and order-independent), from which the caller derives scale = amax / 448. */

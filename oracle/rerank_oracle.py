@@ -164,6 +164,8 @@ _MHA = [multi_head_attention]
 
 _FOLD = [False]
 _FP8 = [False]
+_FP8_DOWN = [False]
+FP8_GELU_MUL = 8.0          # static scale of the e4m3 GELU output (rr_api.hip FP8_GELU_MUL)
 
 
 def q8_rows(x: Tensor) -> Tensor:
@@ -181,6 +183,15 @@ def linear_fp8(x: Tensor, w: Dict[str, Tensor], name: str) -> Tensor:
     return y if b is None else y + b
 
 
+def linear_fp8_static(x: Tensor, w: Dict[str, Tensor], name: str, mul: float = FP8_GELU_MUL) -> Tensor:
+    """y = e4m3(clamp(mul x, +-448)) / mul . q8_rows(W)^T + b: the FFN-down of rr_config.fp8 where it runs on the e4m3 ring —
+    its A operand is the GELU output under ONE static power-of-two scale (gemm_kernel_hp8 EPI 3), its weights per channel."""
+    xq = (x * mul).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * (1.0 / mul)
+    y = xq @ q8_rows(w[name + ".weight"]).t()
+    b = w.get(name + ".bias")
+    return y if b is None else y + b
+
+
 class device_rounding:
     """`with device_rounding(dtype) as mm:` — run the oracle with the device's 16-bit rounding points
     (dtype = torch.bfloat16 for compute_dtype "bf16", torch.float16 for "fp16").  `fp8`: rr_config.fp8 — in the encoder
@@ -189,14 +200,15 @@ class device_rounding:
     the encoder stacks (`encoder_stack`) run with LayerNorm folded into the consumer GEMMs, i.e. the 16-bit operand
     of QKV / FFN-up is the RAW pre-LayerNorm row and the normalisation happens on the fp32 accumulators."""
 
-    def __init__(self, dtype=torch.bfloat16, fold: bool = True, fp8: bool = False):
-        self.dtype, self.fold, self.fp8 = dtype, fold and not fp8, fp8
+    def __init__(self, dtype=torch.bfloat16, fold: bool = True, fp8: bool = False, fp8_down: bool = False):
+        self.dtype, self.fold, self.fp8, self.fp8_down = dtype, fold and not fp8, fp8, fp8 and fp8_down   # fp8_down: FFN-down e4m3 too
 
     def __enter__(self):
         _MHA.append(multi_head_attention_bf16)
         _RDT.append(self.dtype)
         _FOLD.append(self.fold)
         _FP8.append(self.fp8)
+        _FP8_DOWN.append(self.fp8_down)
         return mm_bf16
 
     def __exit__(self, *a):
@@ -204,6 +216,7 @@ class device_rounding:
         _RDT.pop()
         _FOLD.pop()
         _FP8.pop()
+        _FP8_DOWN.pop()
         return False
 
 
@@ -239,7 +252,8 @@ def encoder_stack(h: Tensor, w: Dict[str, Tensor], prefix: str, n_layers: int, h
             ctx = _MHA[-1](q, k, v, heads, add_mask)
             a = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + h, w, p + ".attention.output.LayerNorm", eps)
             inter = gelu_erf(linear_fp8(a, w, p + ".intermediate.dense"))
-            h = layer_norm(linear(inter, w, p + ".output.dense", mm) + a, w, p + ".output.LayerNorm", eps)
+            down = linear_fp8_static(inter, w, p + ".output.dense") if _FP8_DOWN[-1] else linear(inter, w, p + ".output.dense", mm)
+            h = layer_norm(down + a, w, p + ".output.LayerNorm", eps)
             if taps is not None:
                 taps[f"{tap_name}{i}"] = h
         return h

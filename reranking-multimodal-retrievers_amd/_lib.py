@@ -88,6 +88,8 @@ _SIGS = {
     "rr_op_amax": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rr_op_gemm_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rr_op_gemm_fp8_rc": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rr_op_gemm_fp8_gelu_e4m3": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rr_op_gemm_fp8_resid": (C.c_int, [_P, _P, _P, C.c_float, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rr_op_layernorm_q8": (C.c_int, [_P, _P, _P, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
     "rr_util_quantize_rows_e4m3": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "rr_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),

@@ -146,15 +146,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_f8(const uint8_t* __r
 // {A rows 0-127, B rows 0-127, B rows 128-255, A rows 128-255} x 2 tile parities, refilled by LDS-DMA as soon as a slot's
 // fragments are in registers; per K-tile 4 phases (quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0)), each two blocks of
 // 2 MFMAs (k-step 0, k-step 1), fragments read one block ahead; sync points X (after p1) and Y (after p3) with the same
-// counted vmcnt literals as gemm_kernel_hp (2 pieces per half-tile per wave).  EPI 0: 16-bit out, 1: 16-bit erf-GELU.
+// counted vmcnt literals as gemm_kernel_hp (2 pieces per half-tile per wave).  EPI 0: 16-bit out, 1: 16-bit erf-GELU,
+// 3: erf-GELU -> e4m3 bytes (x.out_mul, a power of two, is the static scale of the whole tensor: the consumer multiplies its
+// accumulators by 1 / out_mul), 4: fp32 out = acc * s + bias + residual row (optionally LayerNorm-recomputed from its
+// statistics, as gemm_kernel_hp's fp32-stream residual epilogue does) — the FFN-down of the fp8 configuration.
+struct F8Extra {
+  float out_mul = 1.0f;             // EPI 3
+  const float* resid = nullptr;     // EPI 4: residual rows [M, ldr] f32
+  int ldr = 0;
+  const float2* rstats = nullptr;   //        (mean, rstd) per row, or null: the rows are the residual themselves
+  const float* rgamma = nullptr;
+  const float* rbeta = nullptr;
+};
 template <int EPI, int DT>
 __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict__ A, int lda,
                                                       const uint8_t* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, float scale,
                                                       const float* __restrict__ row_scale,
                                                       const float* __restrict__ col_scale,
-                                                      bf16_t* __restrict__ C, int ldc, int M, int N, int Kd,
-                                                      int tiles_n, int nwg) {
+                                                      void* __restrict__ Cv, int ldc, int M, int N, int Kd,
+                                                      int tiles_n, int nwg, F8Extra x) {
+  bf16_t* const C = (bf16_t*)Cv;
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int GROUP = Kd > 2048 ? 1 : (tiles_n > 9 ? 4 : 8);  // L2-aware tile order, as gemm_kernel_hp (K bytes per row: Kd)
@@ -333,7 +345,140 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
   }
 
   // ---- epilogue of tile (cm0, cn0): v = acc * (scale * sa[m] * sw[n]) + bias[n] (+ GELU), 16-bit out, two 128-row passes
-  {
+  if constexpr (EPI == 3) {
+    // e4m3 out: one byte per element, two 128-row passes through a [128][256 + 16] byte image.  A lane owns 4 consecutive
+    // columns = one dword; rows with bit 4 set keep the two 8-byte halves of every 16-byte chunk swapped (rows r and r + 16 of
+    // a ds_write_b32 lane group would meet on the same bank at the 272-byte pitch), the reader swaps them back.
+    constexpr int PITCH = BN + 16, CPR = BN / 16, ROWS = 128;
+    char* const stg = lds + 5 * HALF;
+    uint8_t* const C8 = (uint8_t*)Cv;
+    float rs[2][2];
+#pragma unroll
+    for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int gm = cm0 + hA * 128 + wr * 64 + mb * 32 + (lane & 31);
+        rs[hA][mb] = scale * (row_scale ? row_scale[min(gm, M - 1)] : 1.0f);
+      }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int hA = q >> 1, hB = q & 1;
+        if (hA != pass) continue;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h, gn = cn0 + cn;
+          const bool in = gn < N;
+          const float4 bv = (bias && in) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 cw = (col_scale && in) ? *(const float4*)(col_scale + gn) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const float r_ = rs[hA][mb];
+            const float v0 = fmaf(acc[q][mb][4 * rg + 0], r_ * cw.x, bv.x), v1 = fmaf(acc[q][mb][4 * rg + 1], r_ * cw.y, bv.y),
+                        v2 = fmaf(acc[q][mb][4 * rg + 2], r_ * cw.z, bv.z), v3 = fmaf(acc[q][mb][4 * rg + 3], r_ * cw.w, bv.w);
+            const f32x2 g0 = gelu_erf_fast2(f32x2{v0, v1}), g1 = gelu_erf_fast2(f32x2{v2, v3});
+            int w8 = 0;                                       // (saturating: |gelu| * out_mul beyond 448 clamps)
+            w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(g0.x * x.out_mul, -448.f, 448.f),
+                                                 __builtin_amdgcn_fmed3f(g0.y * x.out_mul, -448.f, 448.f), w8, false);
+            w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(g1.x * x.out_mul, -448.f, 448.f),
+                                                 __builtin_amdgcn_fmed3f(g1.y * x.out_mul, -448.f, 448.f), w8, true);
+            const int r = wr * 64 + mb * 32 + (lane & 31);
+            *(uint32_t*)(stg + r * PITCH + (cn ^ ((r & 16) >> 1))) = (uint32_t)w8;
+          }
+        }
+      }
+      if (pass == 0 && has_next) wait_vmcnt8<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int row_base = cm0 + pass * 128;
+      constexpr int UNR = ROWS * CPR / 512;
+      static_assert(ROWS * CPR == 512 * UNR && UNR == 4, "one batch per pass");
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
+        const int gm = row_base + r, gcol = cn0 + c * 16;
+        if (gm < M && gcol < N) {
+          uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
+          if (tid & 256) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/16 + 32u: bit 4 of r = bit 8 of tid
+          store_stream(C8 + (size_t)gm * ldc + gcol, v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if constexpr (EPI == 4) {
+    // fp32 out + residual: four 64-row passes (pass = 2 hA + wave row group) through a [64][1024 + 16] byte image.  A wave
+    // streams one row per step (its LayerNorm statistics are a scalar load), a thread keeps ONE 4-column chunk for the whole
+    // tile (gamma / beta loaded once); the 8 residual chunks of a pass are requested before the pass's staging writes.
+    constexpr int PITCH = BN * 4 + 16, CPR = BN * 4 / 16, ROWS = 64, UNR = ROWS * CPR / 512;
+    static_assert(ROWS * PITCH <= 5 * HALF && CPR == 64 && UNR == 8, "staging image above the five prefetch slots; one row per wave and step");
+    char* const stg = lds + 5 * HALF;
+    float* const C32 = (float*)Cv;
+    const int c4 = tid & 63, gcol = cn0 + c4 * 4;
+    const bool col_ok = gcol < N;
+    float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x.rstats && col_ok) { lg = *(const float4*)(x.rgamma + gcol); lb = *(const float4*)(x.rbeta + gcol); }
+    float rs[2][2];
+#pragma unroll
+    for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int gm = cm0 + hA * 128 + wr * 64 + mb * 32 + (lane & 31);
+        rs[hA][mb] = scale * (row_scale ? row_scale[min(gm, M - 1)] : 1.0f);
+      }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int hA = pass >> 1, wrp = pass & 1;
+      const int row_base = cm0 + hA * 128 + wrp * 64;
+      float4 xr[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int gm = row_base + wave + 8 * u;
+        xr[u] = (gm < M && col_ok) ? load_stream_f4(x.resid + (size_t)gm * x.ldr + gcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (wr == wrp) {
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB) {
+          const int q = 2 * hA + hB;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h, gn = cn0 + cn;
+            const bool in = gn < N;
+            const float4 bv = (bias && in) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 cw = (col_scale && in) ? *(const float4*)(col_scale + gn) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+              const float r_ = rs[hA][mb];
+              const int r = mb * 32 + (lane & 31);
+              *(float4*)(stg + r * PITCH + cn * 4) =
+                  make_float4(fmaf(acc[q][mb][4 * rg + 0], r_ * cw.x, bv.x), fmaf(acc[q][mb][4 * rg + 1], r_ * cw.y, bv.y),
+                              fmaf(acc[q][mb][4 * rg + 2], r_ * cw.z, bv.z), fmaf(acc[q][mb][4 * rg + 3], r_ * cw.w, bv.w));
+            }
+          }
+        }
+      }
+      if (pass == 0 && has_next) wait_vmcnt8<0>();           // (also the first pass's residual rows)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = wave + 8 * u, gm = row_base + r;
+        if (gm < M && col_ok) {
+          float4 xv = xr[u];
+          if (x.rstats) {
+            const float2 st2 = x.rstats[gm];
+            xv = make_float4((xv.x - st2.x) * st2.y * lg.x + lb.x, (xv.y - st2.x) * st2.y * lg.y + lb.y,
+                             (xv.z - st2.x) * st2.y * lg.z + lb.z, (xv.w - st2.x) * st2.y * lg.w + lb.w);
+          }
+          const float4 f = *(const float4*)(stg + r * PITCH + c4 * 16);
+          store_stream(C32 + (size_t)gm * ldc + gcol, make_float4(f.x + xv.x, f.y + xv.y, f.z + xv.z, f.w + xv.w));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
     constexpr int PITCH = BN * 2 + 16, CPR = BN * 2 / 16, ROWS = 128;
     static_assert(ROWS * PITCH <= 5 * HALF, "staging image must fit above the five prefetch slots");
     char* const stg = lds + 5 * HALF;
@@ -483,11 +628,29 @@ hipError_t rr_launch_amax(const void* x, int x_is_f32, size_t n, float* out, hip
 // A8 [M,Kd] e4m3 bytes (row stride lda bytes), W8 [N,Kd] e4m3 (row stride ldw), bias [N] f32 or null; the accumulators are
 // multiplied by scale * row_scale[m] * col_scale[n] (either vector may be null = 1); C: 16-bit in the operand type dt
 // (epilogue 0, 1) or f32 (2), row stride ldc elements.  Kd % 128 == 0, N % 4 == 0.
+// Epilogues 3 (erf-GELU -> e4m3 bytes scaled by out_mul, C = uint8 [M, ldc]) and 4 (f32 out + residual rows `resid` [M, ldr],
+// LayerNorm-recomputed from rstats / rgamma / rbeta when rstats != null) exist on the persistent ring only: rr_gemm_fp8_ring_ok.
+bool rr_gemm_fp8_ring_ok(int M, int N, int Kd) {
+  return M > 0 && N > 0 && Kd > 0 && !(Kd % BKB) && !(N & 15) && ((M + 255) / 256) * ((N + 255) / 256) >= 512;
+}
 hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* bias, float scale,
                               const float* row_scale, const float* col_scale, void* C, int ldc, int M, int N, int Kd,
-                              int epilogue, int dt, hipStream_t st) {
+                              int epilogue, int dt, hipStream_t st, float out_mul, const float* resid, int ldr,
+                              const float* rstats, const float* rgamma, const float* rbeta) {
   if (M <= 0 || N <= 0 || Kd <= 0 || (Kd % BKB) || (N & 3) || (lda & 15) || (ldw & 15) || (ldc & 3)) return hipErrorInvalidValue;
-  if (epilogue < 0 || epilogue > 2 || (dt != 0 && dt != 1)) return hipErrorInvalidValue;
+  if (epilogue < 0 || epilogue > 4 || (dt != 0 && dt != 1)) return hipErrorInvalidValue;
+  if (epilogue >= 3) {
+    if (!rr_gemm_fp8_ring_ok(M, N, Kd)) return hipErrorInvalidValue;
+    if (epilogue == 3 && (!(out_mul > 0.f) || (ldc & 15))) return hipErrorInvalidValue;
+    if (epilogue == 4 && (!resid || (ldr & 3) || (rstats && (!rgamma || !rbeta)))) return hipErrorInvalidValue;
+  }
+  F8Extra ex;
+  ex.out_mul = out_mul;
+  ex.resid = resid;
+  ex.ldr = ldr;
+  ex.rstats = (const float2*)rstats;
+  ex.rgamma = rgamma;
+  ex.rbeta = rbeta;
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
   int dev = 0;
@@ -513,11 +676,13 @@ hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int l
       if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e; \
       if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev);                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, scale, row_scale, col_scale, (bf16_t*)C, ldc, M, N, \
-                       Kd, tiles_n, nwg);                                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, scale, row_scale, col_scale, C, ldc, M, N,   \
+                       Kd, tiles_n, nwg, ex);                                                                        \
   }
     if (epilogue == 0) { if (dt == 0) RR_HP8(0, 0) else RR_HP8(0, 1) }
-    else { if (dt == 0) RR_HP8(1, 0) else RR_HP8(1, 1) }
+    else if (epilogue == 1) { if (dt == 0) RR_HP8(1, 0) else RR_HP8(1, 1) }
+    else if (epilogue == 3) RR_HP8(3, 0)                    /* (the operand type does not enter an e4m3 / f32 output) */
+    else RR_HP8(4, 0)
 #undef RR_HP8
     return hipGetLastError();
   }

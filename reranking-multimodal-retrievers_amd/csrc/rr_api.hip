@@ -132,8 +132,8 @@ struct LayerW {
   bf16_t *wqkv_f = nullptr, *w1_f = nullptr;
   float *cqkv_f = nullptr, *dqkv_f = nullptr, *c1_f = nullptr, *d1_f = nullptr;
   // fp8 mode (cfg.fp8): e4m3 weights, one scale per output channel
-  uint8_t *wqkv8 = nullptr, *w1_8 = nullptr;
-  float *sqkv = nullptr, *s1 = nullptr;
+  uint8_t *wqkv8 = nullptr, *w1_8 = nullptr, *w2_8 = nullptr;
+  float *sqkv = nullptr, *s1 = nullptr, *s2 = nullptr;
   // cross-attention (transformer mapping network only)
   bf16_t *wq_c = nullptr, *wkv_c = nullptr, *wo_c = nullptr;
   float *bq_c = nullptr, *bkv_c = nullptr, *bo_c = nullptr, *lncg = nullptr, *lncb = nullptr;
@@ -484,6 +484,7 @@ int pack_layer(rr_model* m, const std::string& p, int heads, int Hd, bool cross,
     RR_TRY(up_fp8(m, cat({&HT(m, a + ".self.query.weight"), &HT(m, a + ".self.key.weight"), &HT(m, a + ".self.value.weight")}, qs),
                   (size_t)Hd, &L->wqkv8, &L->sqkv));
     RR_TRY(up_fp8(m, HT(m, p + ".intermediate.dense.weight"), (size_t)Hd, &L->w1_8, &L->s1));
+    RR_TRY(up_fp8(m, HT(m, p + ".output.dense.weight"), (size_t)m->cfg.intermediate, &L->w2_8, &L->s2));
   }
   if (!cross) {   // plain encoder layers: folded forms for the LayerNorm -> QKV and LayerNorm -> FFN-up seams
     RR_TRY(up_folded(m, HT(m, p + ".intermediate.dense.weight"), HT(m, p + ".intermediate.dense.bias"),
@@ -721,6 +722,8 @@ struct ResidSrc {
   RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, 2.0) + 8.0 * (M),                              \
          rr_launch_gemm_fold(A, lda, Wf, K, dvec, nullptr, 0, nullptr, nullptr, nullptr, fold, C, ldc, M, N, K, epi, m->dt, st))
 
+int g_fp8_ffn_down = 1;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too
+constexpr float FP8_GELU_MUL = 8.0f;     // static scale of the e4m3 GELU output feeding it
 int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
 
 // One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
@@ -809,9 +812,23 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 5.0 * rows * Hd,
            rr_launch_layernorm_q8(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, (uint8_t*)w.h16, w.rowscale, w.stats_a, st));
-    RR_GEMM_FP8(m, st, w.h16, Hd, L.w1_8, L.b1, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 1);
     const ResidSrc r1{w.pre, w.stats_a, L.ln1g, L.ln1b};
-    RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
+    // FFN-down on the e4m3 ring as well (rr_set_tuning "fp8_ffn_down", default 1) where both GEMMs of the FFN run the
+    // persistent kernel: the GELU epilogue of FFN-up emits e4m3 bytes under ONE static power-of-two scale (GELU's range is
+    // [-0.17, max pre-activation]: x 8 keeps 3 mantissa bits down to 2e-3 and saturates at 56), FFN-down multiplies its
+    // accumulators by 1/8 and its per-channel weight scales and adds the LayerNorm-recomputed residual row in its epilogue
+    const bool down8 = g_fp8_ffn_down && L.w2_8 && (I % 128 == 0) && rr_gemm_fp8_ring_ok(rows, I, Hd) && rr_gemm_fp8_ring_ok(rows, Hd, I);
+    if (down8) {
+      RR_RUN(m, st, RR_K_GEMM_FP8, gemm_flops(rows, I, Hd), 1.0 * rows * Hd + 1.0 * I * Hd + 1.0 * rows * I + 4.0 * rows,
+             rr_launch_gemm_fp8((const uint8_t*)w.h16, Hd, L.w1_8, Hd, L.b1, 1.0f, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 3, m->dt, st,
+                                FP8_GELU_MUL));
+      RR_RUN(m, st, RR_K_GEMM_FP8, gemm_flops(rows, Hd, I), 1.0 * rows * I + 1.0 * Hd * I + 8.0 * rows * Hd + 8.0 * rows,
+             rr_launch_gemm_fp8((const uint8_t*)w.mid, I, L.w2_8, I, L.b2, 1.0f / FP8_GELU_MUL, nullptr, L.s2, w.pre2, Hd, rows, Hd, I, 4,
+                                m->dt, st, 1.0f, r1.x, Hd, r1.stats, r1.g, r1.b));
+    } else {
+      RR_GEMM_FP8(m, st, w.h16, Hd, L.w1_8, L.b1, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 1);
+      RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
+    }
     if (want_h32) {
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
              rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_f32 ? w.h32 : nullptr, w.h16, w.stats_b,
@@ -1766,6 +1783,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!key) return RR_ERR_BAD_ARG;
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
+  if (!strcmp(key, "fp8_ffn_down")) { g_fp8_ffn_down = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
@@ -1805,6 +1823,21 @@ static int rr_op_gemm_fp8_rc_impl(const uint8_t* A8, const uint8_t* W8, const fl
   if (epilogue < 0 || epilogue > 2) return RR_ERR_BAD_ARG;
   hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, 1.0f, row_scale, col_scale, out, N, M, N, K, epilogue, g_op_dt,
                                     (hipStream_t)hip_stream);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+static int rr_op_gemm_fp8_gelu_e4m3_impl(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale,
+                                         const float* col_scale, float out_mul, int M, int N, int K, uint8_t* out8, void* hip_stream) {
+  if (!A8 || !W8 || !out8) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, 1.0f, row_scale, col_scale, out8, N, M, N, K, 3, g_op_dt, (hipStream_t)hip_stream,
+                                    out_mul);
+  return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
+}
+static int rr_op_gemm_fp8_resid_impl(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, const float* col_scale,
+                                     const float* resid, const float* stats, const float* gamma, const float* beta, int M, int N,
+                                     int K, float* out, void* hip_stream) {
+  if (!A8 || !W8 || !out || !resid) return RR_ERR_BAD_ARG;
+  hipError_t e = rr_launch_gemm_fp8(A8, K, W8, K, bias, scale, nullptr, col_scale, out, N, M, N, K, 4, g_op_dt, (hipStream_t)hip_stream,
+                                    1.0f, resid, N, stats, gamma, beta);
   return e == hipSuccess ? RR_OK : (e == hipErrorInvalidValue ? RR_ERR_BAD_SHAPE : RR_ERR_HIP);
 }
 static int rr_op_layernorm_q8_impl(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
@@ -2004,6 +2037,15 @@ int rr_op_gemm_lnfold(const uint16_t* A_raw, const uint16_t* W_folded, const flo
 int rr_op_gemm_fp8_rc(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
                       int M, int N, int K, int epilogue, void* out, void* hip_stream) {
   return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_rc_impl(A8, W8, bias, row_scale, col_scale, M, N, K, epilogue, out, hip_stream); });
+}
+int rr_op_gemm_fp8_gelu_e4m3(const uint8_t* A8, const uint8_t* W8, const float* bias, const float* row_scale, const float* col_scale,
+                             float out_mul, int M, int N, int K, uint8_t* out8, void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_gelu_e4m3_impl(A8, W8, bias, row_scale, col_scale, out_mul, M, N, K, out8, hip_stream); });
+}
+int rr_op_gemm_fp8_resid(const uint8_t* A8, const uint8_t* W8, const float* bias, float scale, const float* col_scale,
+                         const float* resid, const float* stats, const float* gamma, const float* beta, int M, int N, int K, float* out,
+                         void* hip_stream) {
+  return guarded(nullptr, [&]() -> int { return rr_op_gemm_fp8_resid_impl(A8, W8, bias, scale, col_scale, resid, stats, gamma, beta, M, N, K, out, hip_stream); });
 }
 int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols, uint8_t* out8,
                        float* row_scale, float* stats, void* hip_stream) {

@@ -299,7 +299,10 @@ hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float 
 // fp8 (csrc/gemm_fp8.hip, elementwise.hip)
 hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* bias, float scale,
                               const float* row_scale, const float* col_scale, void* C, int ldc, int M, int N, int Kd,
-                              int epilogue, int dt, hipStream_t st);
+                              int epilogue, int dt, hipStream_t st, float out_mul = 1.0f, const float* resid = nullptr,
+                              int ldr = 0, const float* rstats = nullptr, const float* rgamma = nullptr,
+                              const float* rbeta = nullptr);
+bool rr_gemm_fp8_ring_ok(int M, int N, int Kd);   // the shapes whose e4m3 GEMM runs on the persistent ring (epilogues 3 / 4 exist there only)
 hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const float* beta, float eps, int rows, int cols,
                                   uint8_t* out8, float* row_scale, float* stats_out, hipStream_t st);
 
