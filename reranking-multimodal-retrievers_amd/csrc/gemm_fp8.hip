@@ -347,8 +347,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
   // ---- epilogue of tile (cm0, cn0): v = acc * (scale * sa[m] * sw[n]) + bias[n] (+ GELU), 16-bit out, two 128-row passes
   if constexpr (EPI == 3) {
     // e4m3 out: one byte per element, two 128-row passes through a [128][256 + 16] byte image.  A lane owns 4 consecutive
-    // columns = one dword; rows with bit 4 set keep the two 8-byte halves of every 16-byte chunk swapped (rows r and r + 16 of
-    // a ds_write_b32 lane group would meet on the same bank at the 272-byte pitch), the reader swaps them back.
+    // columns = one dword.  ds_write_b32 has 32 banks and its lane groups are 32 rows of one column: at the 272-byte pitch
+    // rows r, r + 8, r + 16, r + 24 would meet on one bank (4-way), so the dword index inside every 16-byte chunk is XORed
+    // with (r >> 3) & 3 and the reader undoes the permutation (first version: halves swapped on bit 4 only, 2-way,
+    // SQ_LDS_BANK_CONFLICT 9.8 % of the kernel's LDS cycles).
     constexpr int PITCH = BN + 16, CPR = BN / 16, ROWS = 128;
     char* const stg = lds + 5 * HALF;
     uint8_t* const C8 = (uint8_t*)Cv;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
             w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(g1.x * x.out_mul, -448.f, 448.f),
                                                  __builtin_amdgcn_fmed3f(g1.y * x.out_mul, -448.f, 448.f), w8, true);
             const int r = wr * 64 + mb * 32 + (lane & 31);
-            *(uint32_t*)(stg + r * PITCH + (cn ^ ((r & 16) >> 1))) = (uint32_t)w8;
+            *(uint32_t*)(stg + r * PITCH + (cn ^ (((r >> 3) & 3) << 2))) = (uint32_t)w8;
           }
         }
       }
@@ -399,9 +401,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
         const int i = tid + u * 512, r = i / CPR, c = i - r * CPR;
         const int gm = row_base + r, gcol = cn0 + c * 16;
         if (gm < M && gcol < N) {
-          uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
-          if (tid & 256) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/16 + 32u: bit 4 of r = bit 8 of tid
-          store_stream(C8 + (size_t)gm * ldc + gcol, v);
+          const uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
+          // r = tid/16 + 32u: (r >> 3) & 3 = (tid >> 7) & 3 = k; dword j of the chunk holds columns 4 (j ^ k): two conditional swaps
+          const bool k0 = (tid & 128) != 0, k1 = (tid & 256) != 0;
+          const uint32_t a0 = k0 ? v.y : v.x, a1 = k0 ? v.x : v.y, a2 = k0 ? v.w : v.z, a3 = k0 ? v.z : v.w;      // j ^ 1
+          store_stream(C8 + (size_t)gm * ldc + gcol, make_uint4(k1 ? a2 : a0, k1 ? a3 : a1, k1 ? a0 : a2, k1 ? a1 : a3));   // j ^ 2
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
