@@ -257,6 +257,38 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
   }
 #define RR_KEEP6() asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(B0K0));
 
+  // Per-row / per-column parameters of the tile (row scales, column scales, bias; EPI 4: gamma, beta) reach [152 KiB, 160 KiB)
+  // by dword LDS-DMA pieces issued BEFORE the tile's first ring refill — as in gemm_kernel_hp: a global load in the epilogue
+  // would queue behind the ten pieces of the next tile's prefetch in the wave's in-order vmcnt queue (80 KiB first); older
+  // than every refill, the pieces only make the loop's counted waits stricter.  Absent vectors: the block holds 1 / 1 / 0.
+  constexpr int PARAM_OFF = 152 * 1024;     // +0 row_scale[256], +1024 col_scale[256], +2048 bias[256], +3072 gamma, +4096 beta
+  {
+    float* const pb = (float*)(lds + PARAM_OFF);
+    if (tid < 256) {
+      if (!row_scale) pb[tid] = 1.0f;
+      if (!col_scale) pb[256 + tid] = 1.0f;
+      if (!bias) pb[512 + tid] = 0.0f;
+    }
+  }
+  auto stage_params = [&](int m0_, int n0_) {
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));     // opaque: recomputed per tile, not hoisted out of the tile loop and spilled
+    const int ln_ = lane_;
+    if (wave < 4) {
+      if (row_scale) glds4_so(row_scale + m0_, (uint32_t)(min(wave * 64 + ln_, M - 1 - m0_) * 4),
+                              __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + wave * 256));
+      if (col_scale) glds4_so(col_scale + n0_, (uint32_t)(min(wave * 64 + ln_, N - 1 - n0_) * 4),
+                              __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 1024 + wave * 256));
+      if (EPI == 4 && x.rstats) glds4_so(x.rgamma + n0_, (uint32_t)(min(wave * 64 + ln_, N - 1 - n0_) * 4),
+                                         __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 3072 + wave * 256));
+    } else {
+      if (bias) glds4_so(bias + n0_, (uint32_t)(min((wave - 4) * 64 + ln_, N - 1 - n0_) * 4),
+                         __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 2048 + (wave - 4) * 256));
+      if (EPI == 4 && x.rstats) glds4_so(x.rbeta + n0_, (uint32_t)(min((wave - 4) * 64 + ln_, N - 1 - n0_) * 4),
+                                         __builtin_amdgcn_readfirstlane(lds_base + PARAM_OFF + 4096 + (wave - 4) * 256));
+    }
+  };
+  stage_params(m0, n0);
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
   RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2)
   bool first_tile = true;
@@ -345,6 +377,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
   }
 
   // ---- epilogue of tile (cm0, cn0): v = acc * (scale * sa[m] * sw[n]) + bias[n] (+ GELU), 16-bit out, two 128-row passes
+  {
+  // per-lane addresses from an OPAQUE thread index, recomputed per tile: visible, the (tile-invariant) LDS addresses of the
+  // parameter reads are hoisted out of the tile loop, kept live across the main loop at 256 VGPRs and spilled (gemm_kernel_hp)
+  int tid_o_ = tid;
+  asm volatile("" : "+v"(tid_o_));
+  const int tid = tid_o_, lane = tid_o_ & 63, h = (tid_o_ & 63) >> 5;
   if constexpr (EPI == 3) {
     // e4m3 out: one byte per element, two 128-row passes through a [128][256 + 16] byte image.  A lane owns 4 consecutive
     // columns = one dword.  ds_write_b32 has 32 banks and its lane groups are 32 rows of one column: at the 272-byte pitch
@@ -359,8 +397,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
     for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const int gm = cm0 + hA * 128 + wr * 64 + mb * 32 + (lane & 31);
-        rs[hA][mb] = scale * (row_scale ? row_scale[min(gm, M - 1)] : 1.0f);
+        rs[hA][mb] = scale * *(const float*)(lds + PARAM_OFF + (hA * 128 + wr * 64 + mb * 32 + (lane & 31)) * 4);
       }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -370,10 +407,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
         if (hA != pass) continue;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h, gn = cn0 + cn;
-          const bool in = gn < N;
-          const float4 bv = (bias && in) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 cw = (col_scale && in) ? *(const float4*)(col_scale + gn) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h;
+          const float4 bv = *(const float4*)(lds + PARAM_OFF + 2048 + cn * 4);      // (columns beyond N repeat the last one; never stored)
+          const float4 cw = *(const float4*)(lds + PARAM_OFF + 1024 + cn * 4);
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
             const float r_ = rs[hA][mb];
@@ -422,14 +458,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
     const int c4 = tid & 63, gcol = cn0 + c4 * 4;
     const bool col_ok = gcol < N;
     float4 lg = make_float4(1.f, 1.f, 1.f, 1.f), lb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x.rstats && col_ok) { lg = *(const float4*)(x.rgamma + gcol); lb = *(const float4*)(x.rbeta + gcol); }
+    if (x.rstats) { lg = *(const float4*)(lds + PARAM_OFF + 3072 + c4 * 16); lb = *(const float4*)(lds + PARAM_OFF + 4096 + c4 * 16); }
     float rs[2][2];
 #pragma unroll
     for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const int gm = cm0 + hA * 128 + wr * 64 + mb * 32 + (lane & 31);
-        rs[hA][mb] = scale * (row_scale ? row_scale[min(gm, M - 1)] : 1.0f);
+        rs[hA][mb] = scale * *(const float*)(lds + PARAM_OFF + (hA * 128 + wr * 64 + mb * 32 + (lane & 31)) * 4);
       }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -447,10 +482,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
           const int q = 2 * hA + hB;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h, gn = cn0 + cn;
-            const bool in = gn < N;
-            const float4 bv = (bias && in) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 cw = (col_scale && in) ? *(const float4*)(col_scale + gn) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h;
+            RR_SBAR();      // (left free, hipcc hoists all sixteen parameter reads of the pass above the residual loads and spills)
+            const float4 bv = *(const float4*)(lds + PARAM_OFF + 2048 + cn * 4);
+            const float4 cw = *(const float4*)(lds + PARAM_OFF + 1024 + cn * 4);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
               const float r_ = rs[hA][mb];
@@ -459,6 +494,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
                   make_float4(fmaf(acc[q][mb][4 * rg + 0], r_ * cw.x, bv.x), fmaf(acc[q][mb][4 * rg + 1], r_ * cw.y, bv.y),
                               fmaf(acc[q][mb][4 * rg + 2], r_ * cw.z, bv.z), fmaf(acc[q][mb][4 * rg + 3], r_ * cw.w, bv.w));
             }
+            RR_SBAR();
           }
         }
       }
@@ -491,8 +527,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
     for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
-        const int gm = cm0 + hA * 128 + wr * 64 + mb * 32 + (lane & 31);
-        rs[hA][mb] = scale * (row_scale ? row_scale[min(gm, M - 1)] : 1.0f);
+        rs[hA][mb] = scale * *(const float*)(lds + PARAM_OFF + (hA * 128 + wr * 64 + mb * 32 + (lane & 31)) * 4);
       }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                   // pass = hA: scale, bias (+ GELU), pack and stage this row half
@@ -502,10 +537,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
         if (hA != pass) continue;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h, gn = cn0 + cn;
-          const bool in = gn < N;
-          const float4 bv = (bias && in) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 cw = (col_scale && in) ? *(const float4*)(col_scale + gn) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const int cn = hB * 128 + wc * 32 + 8 * rg + 4 * h;
+          const float4 bv = *(const float4*)(lds + PARAM_OFF + 2048 + cn * 4);      // (columns beyond N repeat the last one; never stored)
+          const float4 cw = *(const float4*)(lds + PARAM_OFF + 1024 + cn * 4);
 #pragma unroll
           for (int mb = 0; mb < 2; ++mb) {
             const float r_ = rs[hA][mb];
@@ -543,8 +577,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
       __builtin_amdgcn_s_barrier();                          // staging image consumed
     }
   }
+  }   // opaque-index scope of the epilogue
   first_tile = false;
   if (!has_next) break;
+  stage_params(m0, n0);                                     // the NEXT tile's (this tile's epilogue has read its own)
   RR_DMA(1, 1) RR_DMA(1, 2)                                 // slots 5, 6 were under the staging image until now
   }   // output tiles
 #undef RR_SETUP_SRC
