@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
   bf16_t* const C = (bf16_t*)Cv;
   constexpr int BM = 256, BN = 256, HALF = 128 * 128;       // half-tile = 128 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int GROUP = Kd > 2048 ? 1 : (tiles_n > 9 ? 4 : 8);  // L2-aware tile order, as gemm_kernel_hp (K bytes per row: Kd)
+  const int GROUP = Kd > 2048 ? 1 : 8;                      // L2-aware tile order, as gemm_kernel_hp (K bytes per row: Kd)
 
   const int bid = blockIdx.x, gstep = (int)(gridDim.x >> 3);
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp8(const uint8_t* __restrict
         if (gm < M && gcol < N) {
           uint4 v = *(const uint4*)(stg + r * PITCH + c * 16);
           if (tid & 256) v = make_uint4(v.z, v.w, v.x, v.y);   // r = tid/32 + 16u: bit 3 of r = bit 8 of tid
-          *(uint4*)((char*)C + ((size_t)gm * ldc + gcol) * 2) = v;
+          store_stream((char*)C + ((size_t)gm * ldc + gcol) * 2, v);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
