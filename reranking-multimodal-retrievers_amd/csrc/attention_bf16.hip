@@ -454,8 +454,16 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
 // a wave's tile is one serial chain K reads -> MFMA -> softmax -> MFMA): the two chains give the scheduler independent
 // work to put under each other's MFMA and LDS latencies, and K/V fragments, LDS traffic and DMA pieces per query are
 // halved.  ~240 VGPRs, 2 waves per SIMD.  Same arithmetic per row as attn_block<FIXED = true>; same return value.
-template <int DT>
+// DIAG64: s_memtime marks per KV tile (tools/attn_timeline64.py), summed per wave into a.stamps[(block * 4 + wave) * 8 + k]:
+// k = 0 next-tile DMA issue + K fragment requests, 1 QK^T issue (+ V fragment requests), 2 softmax (includes waiting for the
+// QK^T results), 3 pack + P.V issue, 4 the block's PROLOGUE (once), 5 wait for the next tile's DMA + workgroup barrier,
+// 6 tiles, 7 whole block.
+template <int DT, bool DIAG64 = false>
 __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char* const lds, const AttnArgs& a) {
+  unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmk[7];
+#define RR_MK(k) { if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tmk[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } }
+  unsigned long long t_blk0 = 0;
+  if constexpr (DIAG64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_blk0) :: "memory");
   char* const k_img = lds;
   char* const v_img = lds + 2 * TILE_BYTES;
   float* const b_all = (float*)(lds + 4 * TILE_BYTES);
@@ -516,12 +524,14 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       load_bias_chunk(b_all, f_all, key_bias, b, Tk, t / BIAS_TILES);
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
+    RR_MK(0)
     if (t + 1 < nt) load_tile(t + 1, buf ^ 1);
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
     const float* bt_ = b_all + (t & (BIAS_TILES - 1)) * KT;
     const int tile_flags = __builtin_amdgcn_readfirstlane(f_all[t & (BIAS_TILES - 1)]);   // bit 0: some key has a bias; bit 1: no valid key
     const bool masked = (tile_flags & 1) != 0;
+    if constexpr (DIAG64) { for (int k_ = 1; k_ < 5; ++k_) tmk[k_] = tmk[0]; }
     if (!(tile_flags & 2)) {     // a tile without a valid key adds exactly 0: skipped (see attn_block)
 
     // all eight K fragments of the tile are requested before the first MFMA and all eight V fragments before the softmax
@@ -534,6 +544,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       kf[2 * i + 1] = *(const bf16x8*)(kt_ + swz128(32 + (lane & 31), 2 * i + h));
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[1]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     {
     f32x16 s[2][2];     // [sub-block][key half]
     auto qk = [&]() __attribute__((always_inline)) {
@@ -582,6 +593,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       vf[2 * ks + 1] = tr_pair(vt_, key0, 4 + cg, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[2]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     if (__builtin_expect(need_ref, 0)) {
       bool got = false;
 #pragma unroll
@@ -617,6 +629,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       }
       l_run[sb] += acc2[0] + acc2[1];
     }
+    if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[3]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     if (prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -636,10 +649,20 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     }
     if (prio) __builtin_amdgcn_s_setprio(0);
     }   // serial form
+    if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[4]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }   // tile with a valid key
     if (t + 1 < nt) write_tile(buf ^ 1);
     __syncthreads();
+    RR_MK(5)
+    if constexpr (DIAG64) {
+#pragma unroll
+      for (int k_ = 0; k_ < 4; ++k_) dg[k_] += tmk[k_ + 1] - tmk[k_];
+      dg[5] += tmk[5] - tmk[4];           // wait for the next tile's DMA + workgroup barrier
+      dg[6] += 1;
+      if (t == 0) dg[4] = tmk[0] - t_blk0;     // prologue: Q loads, first K/V tile, bias chunk, barrier
+    }
   }
+#undef RR_MK
 
   constexpr float L_MAX = DT == 1 ? 6.0e4f : 1.8e19f;
   bool bad = need_ref;
@@ -655,6 +678,15 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     if (row0 < Tq)
       store_o_rows<64>(lds + wave * (64 * O_PITCH), lane, a.out + ((size_t)b * Tq + row0) * a.out_stride + head * 64,
                        a.out_stride, Tq - row0);
+  }
+  if constexpr (DIAG64) {
+    if (a.stamps && lane == 0) {
+      unsigned long long t_end;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory");
+      dg[7] = t_end - t_blk0;
+#pragma unroll
+      for (int k_ = 0; k_ < 8; ++k_) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + k_] = dg[k_];
+    }
   }
   return __syncthreads_or(bad) != 0;
 }
@@ -677,11 +709,11 @@ __global__ __launch_bounds__(256, 4) void attn_fixed_kernel(const AttnArgs a) {
 }
 
 // Fixed-reference form, 256 query rows per workgroup (64 per wave); flags are per 256-row workgroup.
-template <int DT>
+template <int DT, bool DIAG64 = false>
 __global__ __launch_bounds__(256, 2) void attn_fixed64_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
   int grp, qblk;
-  const bool redo = block_map(blockIdx.x, (a.Tq + 255) >> 8, a.groups, grp, qblk) && attn_block64<DT>(grp, qblk, lds, a);
+  const bool redo = block_map(blockIdx.x, (a.Tq + 255) >> 8, a.groups, grp, qblk) && attn_block64<DT, DIAG64>(grp, qblk, lds, a);
   if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
 }
 
@@ -797,14 +829,16 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
     // per query row (the launch is clock-limited by power: fewer LDS bytes per MFMA is what it answers to), at 2 waves per
     // SIMD; padding to 256 rows must not cost more than that saves.
     const bool rows64 = g_attn_fixed_host == 2 || (g_attn_fixed_host == 3 && ((Tq + 255) / 256) * 2 == (Tq + 127) / 128);
-    if (rows64 && !diag) {
+    if (rows64 && (!diag || g_attn_fixed_host == 2)) {     // (stamps + attn_fixed_ref 2: the 64-row form's own timeline)
       const long nblk64 = ((groups + 7) / 8) * 8 * ((Tq + 255) / 256);
       a.nblk = (int)nblk64;
       hipError_t e = attn_flags(nblk64, st, &a.flags);
       if (e != hipSuccess) return e;
       const dim3 grid64((unsigned)nblk64), rgrid((unsigned)((nblk64 + REDO_SPAN - 1) / REDO_SPAN));
-      if (dt == 0) hipLaunchKernelGGL((attn_fixed64_kernel<0>), grid64, block, 0, st, a);
+      if (diag) hipLaunchKernelGGL((attn_fixed64_kernel<0, true>), grid64, block, 0, st, a);
+      else if (dt == 0) hipLaunchKernelGGL((attn_fixed64_kernel<0>), grid64, block, 0, st, a);
       else hipLaunchKernelGGL((attn_fixed64_kernel<1>), grid64, block, 0, st, a);
+      a.stamps = nullptr;
       if (dt == 0) hipLaunchKernelGGL((attn_redo_kernel<0, 2>), rgrid, block, 0, st, a);
       else hipLaunchKernelGGL((attn_redo_kernel<1, 2>), rgrid, block, 0, st, a);
       return hipGetLastError();
