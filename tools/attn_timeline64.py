@@ -35,7 +35,7 @@ def run():
                                     out.data_ptr(), H, st)
 
 
-for _ in range(3):
+for _ in range(30):                 # the first ~10 launches of a process run at a lower clock: 1.15 ms against 0.91 warm
     assert run() == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
