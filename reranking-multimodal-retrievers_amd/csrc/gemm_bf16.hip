@@ -926,15 +926,28 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // 32-deep k-steps of a fragment differ by chunk ^ 4 = byte offset ^ 64
   const int a_off = swz128(wr * 64 + (lane & 15), lane >> 4);
   const int b_off = swz128(wc * 32 + (lane & 15), lane >> 4);
+  // DIAG, stagger_unit 62 / 63: every fragment read is issued twice / three times (the copies go to a scratch register quad):
+  // what the main loop pays per EXTRA LDS read — i.e. what a wave tile with more operand reuse could win
+  // (tools/gemm_epilogue_timeline.py --stagger 62).  Same operands, same MFMA work: only the LDS traffic changes.
+  // (DIAG 3 = DIAG 1 + these reads: a build of its own, the loop around the copies costs the DIAG 1 timeline 18 % of its main loop)
+  const int lds_dup = (DIAG == 3 && (stagger_unit == 62 || stagger_unit == 63)) ? stagger_unit - 61 : 0;     // 64: this build, no copies
+  auto dup_read = [&](const char* p_) {
+    if constexpr (DIAG == 3) {
+      for (int d_ = 0; d_ < lds_dup; ++d_) {
+        f32x4 scratch_;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(scratch_) : "v"(lds_addr(p_)) : "memory");
+      }
+    }
+  };
   auto read_a = [&](const char* slot, int ks, bf16x8 (&f)[4]) {
     const char* b = slot + (ks ? (a_off ^ 64) : a_off);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) f[mt] = *(const bf16x8*)(b + mt * 2048);
+    for (int mt = 0; mt < 4; ++mt) { f[mt] = *(const bf16x8*)(b + mt * 2048); dup_read(b + mt * 2048); }
   };
   auto read_b = [&](const char* slot, int ks, bf16x8 (&f)[2]) {
     const char* b = slot + (ks ? (b_off ^ 64) : b_off);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(b + nt * 2048);
+    for (int nt = 0; nt < 2; ++nt) { f[nt] = *(const bf16x8*)(b + nt * 2048); dup_read(b + nt * 2048); }
   };
 
   f32x4 acc[4][2][4];   // [quadrant 2*hA+hB][nt][mt]; lane: m = mt*16 + (lane&15), n = nt*16 + (lane>>4)*4 + reg
@@ -1655,20 +1668,27 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(n_cu), block(512);
   const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
-#define RR_DIAG_LAUNCH(E, S, F)                                                                                           \
+#define RR_DIAG_LAUNCH(E, S, F) RR_DIAG_LAUNCH_D(E, S, F, 1)
+#define RR_DIAG_LAUNCH_D(E, S, F, D)                                                                                      \
   {                                                                                                                       \
-    auto kern = gemm_kernel_hp<E, DT, S, 1, F>;                                                                            \
+    auto kern = gemm_kernel_hp<E, DT, S, D, F>;                                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);         \
     if (e != hipSuccess) return e;                                                                                        \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, tiles_n, nwg, \
-                       g_stamps, ln, desync_arg(Kd, epilogue, nwg, n_cu));                                                                                \
+                       g_stamps, ln, (g_stagger >= 62 && g_stagger <= 64) ? g_stagger : desync_arg(Kd, epilogue, nwg, n_cu));       \
     return hipGetLastError();                                                                                             \
+  }
+  if (g_stagger >= 62 && g_stagger <= 64) {      // duplicated fragment reads (64: the same build without copies): QKV and FFN-down forms only
+    if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH_D(EPI_BIAS_RESID_F32, 3, false, 3)
+    if (epilogue == EPI_BIAS_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH_D(EPI_BIAS_BF16, 0, true, 3)
+    return hipErrorInvalidValue;
   }
   if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
   if (epilogue == EPI_BIAS_RESID_F32 && split == 0 && !ln.x16) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0, false)
   if (epilogue == EPI_BIAS_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0, true)
   if (epilogue == EPI_BIAS_GELU_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0, true)
 #undef RR_DIAG_LAUNCH
+#undef RR_DIAG_LAUNCH_D
   return hipErrorInvalidValue;
 }
 
