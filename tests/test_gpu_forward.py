@@ -527,7 +527,7 @@ def test_length_bucketed_forward_equals_the_padded_forward(name):
     assert torch.equal(again["logits"], ref["logits"])
 
 
-@pytest.mark.parametrize("name", ["c2", "tiny_mm"])
+@pytest.mark.parametrize("name", ["c2", "tiny_mm", "tiny_2h"])
 def test_packed_forward_equals_the_bucketed_and_the_padded_forward(name):
     """RerankEngine.forward_ids_packed (rr_forward_packed): the pairs laid out group after group at their group's row length,
     every GEMM of a layer ONE launch over all rows, attention / embeddings / CLS heads per group.  Must equal the bucketed
@@ -555,6 +555,8 @@ def test_packed_forward_equals_the_bucketed_and_the_padded_forward(name):
         assert torch.equal(got["logits"], bucketed["logits"])
         assert torch.equal(got["order"], bucketed["order"])
         assert torch.equal(got["logits"], ref["logits"])
+        if cfg.loss_fn == "2H_BCE":                       # both heads travel through the packed order and back
+            assert torch.equal(got["logits2"], ref["logits2"])
     assert abs(got["loss"].item() - ref["loss"].item()) < 1e-5
     # host-side lengths (what the tokenizer knows) give the same groups as the device-side derivation
     host = eng.forward_ids_packed(*args, None, granule=gran, want_order=True, lengths=((ids != 0) | (am != 0)).long().mul(torch.arange(1, S + 1)).amax(1).tolist())
