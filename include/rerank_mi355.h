@@ -191,8 +191,10 @@ int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_st
  *       and runs rr_head on the [Bq, K] block.
  * Every GEMM and every LayerNorm statistics pass of a layer runs ONCE over all rows of the call; attention, the embedding
  * gathers and the CLS heads run once per segment.  A pair's logit equals what rr_forward computes for it after
- * rr_set_padded_seq_len(padded_seq_len) at seq_len = seg_len[i] (bit for bit), hence what the padded call computes (bit
- * for bit for text-only models, up to fp32 summation order in the cross-encoder's attention with vision tokens).
+ * rr_set_padded_seq_len(padded_seq_len) at seq_len = seg_len[i], hence what the padded call computes: bit for bit for
+ * text-only models (attention runs the schedule the padded call's grid would choose, whatever the segment's size); with
+ * vision tokens up to fp32 summation order in the cross-encoder's attention and in the per-pair vision GEMMs (1.3e-4 at
+ * 800 pairs, tests/test_gpu_parity_fullsize.py).  For rr_reserve count n_queries = n_pairs (image features are per pair).
  * No reference counterpart (it pads); Python: RerankEngine.forward_ids_packed.  RR_ERR_BAD_SHAPE: more than 64 segments,
  * an empty segment, a length above padded_seq_len or, with image features, below the mapping network's cross-attention
  * window (32). */

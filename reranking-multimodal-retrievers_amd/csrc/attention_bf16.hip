@@ -811,7 +811,10 @@ hipError_t rr_attention_reserve(int B, int heads, int Tq, hipStream_t st) {
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
                                int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st,
-                               const float* dense_bias, int dense_ld) {
+                               const float* dense_bias, int dense_ld, long schedule_blocks) {
+  // schedule_blocks > 0: the grid size that decides between the online and the fixed-reference schedule — a packed forward
+  // (rr_forward_packed) launches one segment at a time and passes the PADDED call's grid, so that every pair runs the
+  // schedule, hence the roundings, of the padded forward however few pairs share its length
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (B <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0 || q_batch_div <= 0 || q_batch_off < 0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 7)) return hipErrorInvalidValue;     // 16-byte row chunks everywhere
@@ -824,7 +827,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
              dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk, g_attn_redo_stats};
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
-  if (g_attn_fixed_host && !dense_bias && nblk >= ATTN_FIXED_MIN_BLOCKS) {
+  if (g_attn_fixed_host && !dense_bias && (schedule_blocks > 0 ? schedule_blocks : nblk) >= ATTN_FIXED_MIN_BLOCKS) {
     // 64 query rows per wave: 256-row workgroups, flags per 256-row workgroup.  Half the K/V fragment reads and DMA pieces
     // per query row (the launch is clock-limited by power: fewer LDS bytes per MFMA is what it answers to), at 2 waves per
     // SIMD; padding to 256 rows must not cost more than that saves.

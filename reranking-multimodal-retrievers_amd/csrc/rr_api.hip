@@ -782,11 +782,13 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   }
   if (segs) {
+    // the schedule (online / fixed reference) of the PADDED call over the same pairs: batch pairs of Tseq rows
+    const long sched = (((long)batch * heads + 7) / 8) * 8 * ((Tseq + 127) / 128);
     for (const SegView& g : *segs) {
       const bf16_t* q0 = w.qkv + g.row0 * 3 * Hd;
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * g.n * (double)g.len * g.len * Hd, 2.0 * 4.0 * g.n * g.len * Hd,
              rr_launch_attention(q0, 3 * Hd, 1, 0, q0 + Hd, q0 + 2 * Hd, 3 * Hd, key_bias + g.row0, g.n, heads, g.len, g.len,
-                                 w.ctx + g.row0 * Hd, Hd, m->dt, st, nullptr, 0));
+                                 w.ctx + g.row0 * Hd, Hd, m->dt, st, nullptr, 0, sched));
     }
   } else {
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
@@ -963,7 +965,8 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
     int folded = OP_NORMALISED;
     for (int l = 0; l < c.ce_layers; ++l)
-      RR_TRY(run_layer(m, st, m->ce_layers[l], n, last.T, Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
+      RR_TRY(run_layer(m, st, m->ce_layers[l], n, packed ? vis_pos0 + (last.T - last.S) : last.T,   // (packed: the padded call's rows per pair, for the attention schedule)
+                       Hc, c.ce_heads, Ic, c.ln_eps, w.ce_bias, w, rs, folded,
                        l == c.ce_layers - 1, true,          // the CLS heads read the fp32 rows of the last layer
                        adj, adj_ld,                         // attention fusion: the same bias in every layer
                        packed ? &view : nullptr));

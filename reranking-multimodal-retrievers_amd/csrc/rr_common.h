@@ -312,7 +312,7 @@ hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const floa
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B,
                                int heads, int Tq, int Tk, bf16_t* out, int out_stride, int dt,
-                               hipStream_t st, const float* dense_bias = nullptr, int dense_ld = 0);
+                               hipStream_t st, const float* dense_bias = nullptr, int dense_ld = 0, long schedule_blocks = 0);
 // dense_bias: optional additive bias [B][Tq][dense_ld] (dense_ld a multiple of 64 >= Tk, zero padded), PreFLMR fusion
 hipError_t rr_launch_fusion_adj(const float* scores, int S, int Tq, int Tc, float mult, int pair0, int n, float* adj, int ld,
                                 hipStream_t st, int row0 = 2);
