@@ -168,7 +168,10 @@ int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, in
  * computes for those pairs: text positions are 0..S-1 either way, padded keys contribute exactly 0 to every softmax, and the
  * vision tokens of the cross-encoder keep the positions S_pad.. they have behind the padded text.  Text-only models: logits bit
  * for bit those of the padded call; with vision tokens the cross-encoder's key tiles are cut at other places, i.e. equal up to
- * fp32 summation order.  0 switches it off.  Python: RerankEngine.forward_ids_bucketed. */
+ * fp32 summation order.  "Bit for bit" holds while the shorter call's attention grid and the padded call's are on the same
+ * side of the 1 024-workgroup threshold between the online and the fixed-reference softmax schedule (a bucket of a few
+ * pairs runs the online form: same values up to rounding); rr_forward_packed has no such condition.  0 switches it off.
+ * Python: RerankEngine.forward_ids_bucketed. */
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
 
 /* Range guard of the 16-bit residual rows.  With the folded LayerNorm the RAW pre-LayerNorm rows are MFMA operands and the
