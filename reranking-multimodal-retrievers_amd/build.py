@@ -65,12 +65,17 @@ def check_no_packed_f32(obj: str) -> None:
         if len(dev) != 1:
             raise RuntimeError(f"no gfx950 code object in {obj}")
         dis = subprocess.run([OBJDUMP, "-d", os.path.join(d, dev[0])], capture_output=True, text=True, check=True).stdout
+        # Hand-written packed-f32 arithmetic exists in ONE place, the GELU Horner chain (rr_common.h gelu_erf_fast2: v_pk_fma_f32
+        # only, every operand VALU-produced).  The rule the build enforces: no v_pk_add / v_pk_mul_f32 at all, and no v_pk_fma_f32
+        # DIRECTLY behind an s_waitcnt (the measured failure is exactly that pair; one instruction in between cured it,
+        # profiles/r02_slp_hazard_isa.txt).  A build that lost -fno-slp-vectorize violates both at once.  (Round 3 tried the
+        # LayerNorm apply of the split residual body as packed operations: this check found `s_waitcnt vmcnt(1)` directly in
+        # front of a packed subtract on freshly loaded fp32 residual rows; restricted to the VALU-fed form it was bit-identical and
+        # bought 0.1 % — not kept.)
         bad = re.findall(r"v_pk_(?:add|mul)_f32[^\n]*", dis)
-        # v_pk_fma_f32 is written by hand in ONE place, the GELU Horner chain (rr_common.h gelu_erf_fast2), whose operands are all
-        # VALU-produced; it must never sit within two instructions behind a wait that releases vector-memory loads
         ins = [l.split("//")[0].strip() for l in dis.splitlines() if l.startswith("\t")]
         for i, l in enumerate(ins):
-            if l.startswith("v_pk_fma_f32") and any("s_waitcnt" in ins[j] and "vmcnt" in ins[j] for j in range(max(0, i - 2), i)):
+            if i and l.startswith("v_pk_fma_f32") and ins[i - 1].startswith("s_waitcnt"):
                 bad.append(l + "   (behind " + ins[i - 1] + ")")
         if bad:
             raise RuntimeError(f"{os.path.basename(obj)}: {len(bad)} packed-f32 instructions in the device code (first: {bad[0].strip()}); "
@@ -102,13 +107,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    rebuilt = {j[-1] for j in jobs}
-    for o in NO_PACKED_F32:
-        obj = os.path.join(objdir, o)
-        if obj in rebuilt:
-            check_no_packed_f32(obj)
     objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
+        # the ISA rule is checked on EVERY link, not only on the objects just compiled: an object that failed the check once
+        # is removed, so that it can never be picked up as "up to date" by the next call (that happened: round 3)
+        for o in NO_PACKED_F32:
+            obj = os.path.join(objdir, o)
+            try:
+                check_no_packed_f32(obj)
+            except RuntimeError:
+                os.remove(obj)
+                raise
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs])
     return LIB
 
