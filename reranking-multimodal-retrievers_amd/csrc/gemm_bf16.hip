@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
           if (ok) {
-            store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+            if constexpr (SPLIT != 4) store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint4(hi[0], hi[1], hi[2], hi[3]));
             if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
               uint32_t lo[4];
 #pragma unroll
@@ -1424,16 +1424,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             }
           }
           // LayerNorm statistics of the 128-column group = the 16 lanes of this DPP row (every lane takes part)
-          const int grp = gcol >> 7;
-          const float rcnt = __builtin_amdgcn_rcpf((float)max(1, min(128, N - (grp << 7))));
-          const float mg = row16_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) * rcnt;
-          float q = 0.f;
-          if (ok) {
+          if constexpr (SPLIT != 4) {           // (SPLIT 4: the plain fp32 stream on this epilogue — no 16-bit copy, no statistics)
+            const int grp = gcol >> 7;
+            const float rcnt = __builtin_amdgcn_rcpf((float)max(1, min(128, N - (grp << 7))));
+            const float mg = row16_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) * rcnt;
+            float q = 0.f;
+            if (ok) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
+              for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
+            }
+            const float m2 = row16_sum(q);
+            if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
           }
-          const float m2 = row16_sum(q);
-          if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
         }
         EP_ADD(8)
         if (pass + 1 < NPASS) issue_resid(pass + 1);
@@ -1569,6 +1571,7 @@ inline int device_cus() {
 }
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
+std::atomic<int> g_resid_fast{1};         // rr_set_tuning("resid_fast"): plain fp32 residual GEMMs on the split forms' epilogue (SPLIT 4)
 std::atomic<int> g_desync{0};             // rr_set_tuning("gemm_desync"): percent of the modelled tile period the eight XCDs are spread over
 // start skew of the persistent kernel, as the kernel's stagger_unit argument (100 + sleeps of 256 cycles per XCD index)
 inline int desync_arg(int Kd, int epilogue, int nwg, int n_cu) {
@@ -1635,6 +1638,11 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
     RR_GEMM_SPLIT_CASE(1)
     RR_GEMM_SPLIT_CASE(2)
     RR_GEMM_SPLIT_CASE(3)
+  }
+  // the plain fp32 residual stream (the fp8 configuration's attention-out, folding switched off) on the split forms' epilogue:
+  // residual rows requested a pass ahead, 8-column chunks (rr_set_tuning "resid_fast", default 1; bit-identical to the older form)
+  if (epilogue == EPI_BIAS_RESID_F32 && resid && !ln.x16 && !ln.in_stats && g_resid_fast.load() && !(N & 7)) {
+    switch (4) { RR_GEMM_SPLIT_CASE(4) }
   }
 #undef RR_GEMM_SPLIT_CASE
   switch (epilogue) {
@@ -1797,6 +1805,7 @@ extern "C" int rr_set_gemm_desync(int pct) {
   g_desync.store(pct);
   return 0;
 }
+extern "C" int rr_set_resid_fast(int on) { g_resid_fast.store(on != 0); return 0; }
 extern "C" int rr_set_gemm_stagger(int unit) {
   if (unit < 0 || unit > 64) return -1;
   g_stagger = unit;
