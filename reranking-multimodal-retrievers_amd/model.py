@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _lib as L
+from .pair_inputs import group_pairs_by_length
 
 
 class RerankOutput(dict):
@@ -375,33 +376,20 @@ class RerankEngine:
         N, S = input_ids.shape
         assert N == Bq * K and granule > 0
         floor = int(self.arch.get("cross_attn_len", 32)) if image_cls is not None else 1   # the mapping network's cross-attention window
-        sizes = sorted({min(S, max(floor, g)) for g in range(granule, S + granule, granule)})
-        if lengths is not None:
-            import numpy as np
-            ln = np.clip(np.asarray(lengths, dtype=np.int64).reshape(-1), 1, S)
-            assert ln.shape[0] == N, "one length per pair"
-            which_h = np.searchsorted(np.asarray(sizes), ln, side="left")      # smallest group length >= len
-            counts = np.bincount(which_h, minlength=len(sizes)).tolist()
-            order = torch.from_numpy(np.argsort(which_h, kind="stable")).to(dev, non_blocking=True)
-        else:
+        if lengths is None:                                            # derived on the device: one device -> host copy
             cols = torch.arange(1, S + 1, device=dev)
-            used = (input_ids != 0) | (attention_mask != 0)
-            lens = (used * cols).amax(1).clamp_(min=1)                     # 1 + index of the last non-pad position
-            which = torch.bucketize(lens, torch.tensor(sizes, device=dev))  # smallest group length >= len
-            counts = torch.bincount(which, minlength=len(sizes)).cpu().tolist()
-            order = torch.argsort(which, stable=True)
+            lengths = (((input_ids != 0) | (attention_mask != 0)) * cols).amax(1).cpu().numpy()
+        order_h, seg_n, seg_len = group_pairs_by_length(lengths, S, granule, floor)
+        assert len(order_h) == N, "one length per pair"
+        order = torch.from_numpy(order_h).to(dev, non_blocking=True)
         parts = [[], [], []]
-        seg_n, seg_len, o = [], [], 0
-        for b, n in enumerate(counts):
-            if n == 0:
-                continue
+        o = 0
+        for n, sb in zip(seg_n, seg_len):
             idx = order[o: o + n]
             o += n
             for dst, t in zip(parts, (input_ids, attention_mask, token_type_ids)):
                 if t is not None:
-                    dst.append(t.index_select(0, idx)[:, :sizes[b]].reshape(-1))
-            seg_n.append(n)
-            seg_len.append(sizes[b])
+                    dst.append(t.index_select(0, idx)[:, :sb].reshape(-1))
         ids_p, am_p = torch.cat(parts[0]), torch.cat(parts[1])
         tt_p = torch.cat(parts[2]) if token_type_ids is not None else None
         cls_p = pat_p = None

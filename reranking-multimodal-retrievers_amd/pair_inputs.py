@@ -108,3 +108,23 @@ class NativePairTokenizer:
         if rc != 0:
             raise ValueError(f"rr_tok_prepare_pairs failed ({rc})")
         return {"input_ids": out[0], "attention_mask": out[1], "token_type_ids": out[2]}
+
+
+def group_pairs_by_length(lengths, padded_len: int, granule: int, min_len: int = 1):
+    """Host side of the packed forward (rr_forward_packed): pairs -> segments of equal row length.
+    `lengths[i]` = token count of pair i (1 + index of its last non-pad position, as the tokenizer knows it), clipped to
+    [1, padded_len]; a pair goes to the smallest multiple of `granule` (at least `min_len`: the mapping network's
+    cross-attention window when image features are present; at most `padded_len`) that holds it.
+    Returns (order, seg_pairs, seg_len): `order` lists the pair indices segment after segment (ascending length, input order
+    kept inside a segment: a stable sort), seg_pairs / seg_len one entry per NON-EMPTY segment.  The reference pads every
+    pair to padded_len (utils.py:157-165): one segment of that length."""
+    import numpy as np
+    if granule <= 0 or padded_len <= 0:
+        raise ValueError("granule and padded_len must be positive")
+    ln = np.clip(np.asarray(lengths, dtype=np.int64).reshape(-1), 1, padded_len)
+    sizes = np.asarray(sorted({min(padded_len, max(int(min_len), g)) for g in range(granule, padded_len + granule, granule)}), dtype=np.int64)
+    which = np.searchsorted(sizes, ln, side="left")               # smallest segment length >= len
+    order = np.argsort(which, kind="stable")
+    counts = np.bincount(which, minlength=len(sizes))
+    keep = counts > 0
+    return order, counts[keep].tolist(), sizes[keep].tolist()

@@ -47,3 +47,26 @@ def test_query_major_order(tok):
     ids = enc["input_ids"]
     red, big = tok.convert_tokens_to_ids("red"), tok.convert_tokens_to_ids("big")
     assert (ids[:2, 1] == red).all() and (ids[2:, 1] == big).all()
+
+
+def test_group_pairs_by_length_segments():
+    """Host side of rr_forward_packed (pair_inputs.group_pairs_by_length): smallest multiple of the granule that holds each
+    pair, stable inside a segment, clipped to [min_len, padded length]; empty segments dropped."""
+    import numpy as np
+    from rmr_amd.pair_inputs import group_pairs_by_length
+    lens = [1, 64, 65, 512, 600, 0, 130, 64, 33]
+    order, n, L = group_pairs_by_length(lens, 512, 64)
+    assert L == [64, 128, 192, 512] and n == [5, 1, 1, 2]
+    assert order.tolist() == [0, 1, 5, 7, 8, 2, 6, 3, 4]                  # ascending segment, input order inside
+    assert sum(n) == len(lens) and all(min(max(lens[i], 1), 512) <= L[s] for s, lo in enumerate(np.cumsum([0] + n[:-1])) for i in order[lo: lo + n[s]])
+    # image features present: no segment below the mapping network's cross-attention window
+    order, n, L = group_pairs_by_length([3, 20, 40], 64, 16, min_len=32)
+    assert L == [32, 48] and n == [2, 1] and order.tolist() == [0, 1, 2]
+    # one segment = the reference's padding; a granule beyond the padded length is that too
+    assert group_pairs_by_length([5, 9], 128, 128)[1:] == ([2], [128])
+    assert group_pairs_by_length([5, 9], 128, 1000)[1:] == ([2], [128])
+    # a padded length that is not a multiple of the granule: the last segment is the padded length itself
+    assert group_pairs_by_length([100], 100, 64)[1:] == ([1], [100])
+    import pytest
+    with pytest.raises(ValueError):
+        group_pairs_by_length([1], 64, 0)
