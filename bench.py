@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--packed", action="store_true",
                     help="packed execution (RerankEngine.forward_ids_packed / rr_forward_packed): the pairs grouped by length in steps "
                          "of --granule rows, every GEMM of a layer ONE launch over the rows that exist; pairs/s still counts padded pairs")
-    ap.add_argument("--granule", type=int, default=64, help="row-length step of --packed")
+    ap.add_argument("--granule", type=int, default=16, help="row-length step of --packed")
     ap.add_argument("--weights-gain", type=float, default=1.0,
                     help="std multiplier of the Linear matrices of the synthetic weights (1 = HF init: near-uniform attention; 2.5 = the "
                          "peaked-attention regime of tests/golden c3_sep).  The line then also reports how many attention workgroups "

@@ -192,7 +192,8 @@ int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_st
  *       pair order, or both NULL (a segment mixes the candidates of several queries);
  *   logits_out (/ logits2_out for 2H_BCE) : DEVICE float32 [n] in the packed pair order; the caller scatters them back
  *       and runs rr_head on the [Bq, K] block.
- * Every GEMM and every LayerNorm statistics pass of a layer runs ONCE over all rows of the call; attention, the embedding
+ * Every GEMM, every LayerNorm statistics pass and the attention of a layer run ONCE over all rows of the call (attention as
+ * one launch over the segments' workgroups when the padded call's grid selects the fixed-reference schedule); the embedding
  * gathers and the CLS heads run once per segment.  A pair's logit equals what rr_forward computes for it after
  * rr_set_padded_seq_len(padded_seq_len) at seq_len = seg_len[i], hence what the padded call computes: bit for bit for
  * text-only models (attention runs the schedule the padded call's grid would choose, whatever the segment's size); with

@@ -749,6 +749,68 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   }
 }
 
+// ---- packed forward (rr_forward_packed): ALL segments of a layer in one launch.  A segment = n pairs of `len` rows each
+// (self-attention, Tq = Tk = len), its rows back to back from row0; blk0[s] = first workgroup of segment s in the 64-row
+// form's grid (a multiple of 8: a workgroup's id modulo 8 stays its XCD inside every segment).  One launch instead of one per
+// segment: no partially filled last round per segment, which is what lets the row granule shrink.
+constexpr int ATTN_MAX_SEGS = 64;
+struct AttnSegs {
+  int nseg;
+  int blk0[ATTN_MAX_SEGS + 1];
+  int len[ATTN_MAX_SEGS];
+  int n[ATTN_MAX_SEGS];
+  long long row0[ATTN_MAX_SEGS];
+};
+__device__ __forceinline__ int seg_of(const AttnSegs& t, const int bid, AttnArgs& b) {      // bid wave-uniform
+  int s = 0;
+  while (s + 1 < t.nseg && bid >= t.blk0[s + 1]) ++s;
+  const long long r0 = t.row0[s];
+  b.q += r0 * b.q_stride;
+  b.k += r0 * b.kv_stride;
+  b.v += r0 * b.kv_stride;
+  if (b.key_bias) b.key_bias += r0;
+  b.out += r0 * b.out_stride;
+  b.Tq = b.Tk = t.len[s];
+  b.groups = t.n[s] * b.heads;
+  return bid - t.blk0[s];
+}
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_fixed64_seg_kernel(const AttnArgs a, const AttnSegs t) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  AttnArgs b = a;
+  const int lbid = seg_of(t, (int)blockIdx.x, b);
+  int grp, qblk;
+  const bool redo = block_map(lbid, (b.Tq + 255) >> 8, b.groups, grp, qblk) && attn_block64<DT>(grp, qblk, lds, b);
+  if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
+}
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_redo_seg_kernel(const AttnArgs a, const AttnSegs t) {
+  __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
+  __shared__ int list[REDO_SPAN];
+  __shared__ int count;
+  if (threadIdx.x == 0) count = 0;
+  __syncthreads();
+  const int id = blockIdx.x * REDO_SPAN + threadIdx.x;
+  if (threadIdx.x < REDO_SPAN && id < a.nblk && a.flags[id]) list[atomicAdd(&count, 1)] = id;
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(count);
+  if (a.redo_stats && threadIdx.x == 0) {
+    atomicAdd(&a.redo_stats[0], (unsigned long long)n);
+    atomicAdd(&a.redo_stats[1], (unsigned long long)min(REDO_SPAN, a.nblk - (int)blockIdx.x * REDO_SPAN));
+  }
+  for (int j = 0; j < n; ++j) {
+    AttnArgs b = a;
+    const int lbid = seg_of(t, __builtin_amdgcn_readfirstlane(list[j]), b);
+    int grp, qblk;
+    if (!block_map(lbid, (b.Tq + 255) >> 8, b.groups, grp, qblk)) continue;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      if ((qblk * 2 + part) * 128 < b.Tq) attn_block<DT, false, false, false>(grp, qblk * 2 + part, lds, b);
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 static unsigned long long* g_attn_stamps = nullptr;
@@ -860,5 +922,51 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
   if (diag) hipLaunchKernelGGL((attn_fwd_kernel<0, false, true>), grid, block, 0, st, a);
   else if (dt == 0) { if (dense_bias) hipLaunchKernelGGL((attn_fwd_kernel<0, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((attn_fwd_kernel<0, false>), grid, block, 0, st, a); }
   else { if (dense_bias) hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, block, 0, st, a); }
+  return hipGetLastError();
+}
+
+// All segments of a packed forward's layer (self-attention, fused-QKV style pointers: row r of the call at q + r * q_stride):
+// one fixed-reference launch + one redo launch when `schedule_blocks` (the padded call's grid) selects that schedule, else one
+// rr_launch_attention per segment (the online form of small calls).  seg_* are HOST arrays.
+hipError_t rr_launch_attention_segs(const bf16_t* q, int q_stride, const bf16_t* k, const bf16_t* v, int kv_stride,
+                                    const float* key_bias, int heads, int nseg, const int* seg_n, const int* seg_len,
+                                    const long long* seg_row0, bf16_t* out, int out_stride, int dt, hipStream_t st,
+                                    long schedule_blocks) {
+  if (dt != 0 && dt != 1) return hipErrorInvalidValue;
+  if (nseg <= 0 || heads <= 0 || !seg_n || !seg_len || !seg_row0) return hipErrorInvalidValue;
+  if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 7)) return hipErrorInvalidValue;
+  const bool one_launch = g_attn_fixed_host && schedule_blocks >= ATTN_FIXED_MIN_BLOCKS && nseg <= ATTN_MAX_SEGS && !g_attn_stamps;
+  if (!one_launch) {
+    for (int s = 0; s < nseg; ++s) {
+      const bf16_t* q0 = q + seg_row0[s] * q_stride;
+      hipError_t e = rr_launch_attention(q0, q_stride, 1, 0, k + seg_row0[s] * kv_stride, v + seg_row0[s] * kv_stride, kv_stride,
+                                         key_bias ? key_bias + seg_row0[s] : nullptr, seg_n[s], heads, seg_len[s], seg_len[s],
+                                         out + seg_row0[s] * out_stride, out_stride, dt, st, nullptr, 0, schedule_blocks);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  AttnSegs t;
+  t.nseg = nseg;
+  long total = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (seg_n[s] <= 0 || seg_len[s] <= 0 || (long)seg_len[s] * kv_stride * 2 >= (1L << 32)) return hipErrorInvalidValue;
+    t.blk0[s] = (int)total;
+    t.len[s] = seg_len[s];
+    t.n[s] = seg_n[s];
+    t.row0[s] = seg_row0[s];
+    total += (((long)seg_n[s] * heads + 7) / 8) * 8 * ((seg_len[s] + 255) / 256);
+    if (total > 0x7fffffffL) return hipErrorInvalidValue;
+  }
+  t.blk0[nseg] = (int)total;
+  AttnArgs a{q, q_stride, 1, 0, k, v, kv_stride, key_bias, heads, 0, 0, out, out_stride, 0,
+             nullptr, 0, nullptr, g_attn_prio_host, nullptr, (int)total, g_attn_redo_stats};
+  hipError_t e = attn_flags(total, st, &a.flags);
+  if (e != hipSuccess) return e;
+  const dim3 grid((unsigned)total), rgrid((unsigned)((total + REDO_SPAN - 1) / REDO_SPAN)), block(256);
+  if (dt == 0) hipLaunchKernelGGL((attn_fixed64_seg_kernel<0>), grid, block, 0, st, a, t);
+  else hipLaunchKernelGGL((attn_fixed64_seg_kernel<1>), grid, block, 0, st, a, t);
+  if (dt == 0) hipLaunchKernelGGL((attn_redo_seg_kernel<0>), rgrid, block, 0, st, a, t);
+  else hipLaunchKernelGGL((attn_redo_seg_kernel<1>), rgrid, block, 0, st, a, t);
   return hipGetLastError();
 }

@@ -783,14 +783,19 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     RR_GEMM(m, st, w.h16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hd, rows, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
   }
   if (segs) {
-    // the schedule (online / fixed reference) of the PADDED call over the same pairs: batch pairs of Tseq rows
+    // the schedule (online / fixed reference) of the PADDED call over the same pairs: batch pairs of Tseq rows; all segments
+    // in ONE launch (rr_launch_attention_segs) where that schedule is the fixed-reference one
     const long sched = (((long)batch * heads + 7) / 8) * 8 * ((Tseq + 127) / 128);
+    std::vector<int> sn, sl;
+    std::vector<long long> sr;
+    double fl = 0.0;
     for (const SegView& g : *segs) {
-      const bf16_t* q0 = w.qkv + g.row0 * 3 * Hd;
-      RR_RUN(m, st, RR_K_ATTENTION, 4.0 * g.n * (double)g.len * g.len * Hd, 2.0 * 4.0 * g.n * g.len * Hd,
-             rr_launch_attention(q0, 3 * Hd, 1, 0, q0 + Hd, q0 + 2 * Hd, 3 * Hd, key_bias + g.row0, g.n, heads, g.len, g.len,
-                                 w.ctx + g.row0 * Hd, Hd, m->dt, st, nullptr, 0, sched));
+      sn.push_back(g.n); sl.push_back(g.len); sr.push_back((long long)g.row0);
+      fl += 4.0 * g.n * (double)g.len * g.len * Hd;
     }
+    RR_RUN(m, st, RR_K_ATTENTION, fl, 2.0 * 4.0 * rows * Hd,
+           rr_launch_attention_segs(w.qkv, 3 * Hd, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, heads, (int)sn.size(), sn.data(),
+                                    sl.data(), sr.data(), w.ctx, Hd, m->dt, st, sched));
   } else {
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
            rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
