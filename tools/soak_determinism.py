@@ -1,4 +1,8 @@
-"""40 forwards of each main configuration (c3 / configs[4] fp8, padded and packed): the logits must hash to ONE value (run-to-run\ndeterminism: no atomics, no order-dependent reductions on the path), stay finite, and leave the fp16 range guard quiet.\n\n    python tools/soak_determinism.py\n"""
+"""40 forwards of each main configuration (c3 / configs[4] fp8, padded and packed): the logits must hash to ONE value (run-to-run
+determinism: no atomics, no order-dependent reductions on the path), stay finite, and leave the fp16 range guard quiet.
+
+    python tools/soak_determinism.py
+"""
 import sys, hashlib
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
