@@ -128,8 +128,8 @@ def test_split_residual_stream_costs_no_accuracy(dt):
         assert between <= 5e-4
 
 
-@pytest.mark.parametrize("vision", [False, True])
-def test_packed_forward_at_the_bench_size(vision):
+@pytest.mark.parametrize("vision,dt", [(False, "fp16"), (True, "fp16"), (False, "bf16")])
+def test_packed_forward_at_the_bench_size(vision, dt):
     """rr_forward_packed at the headline size (8 queries x 100 candidates, S = 512, pair lengths U[64, 512], the c3 shape with
     and without its 81 vision tokens): eight length groups, 258 k of 410 k rows.  Size-independent properties: every pair's
     logit equals the padded forward's (bit for bit text-only; fp32 summation order of the cross-encoder's attention with
@@ -138,7 +138,7 @@ def test_packed_forward_at_the_bench_size(vision):
     import rmr_amd
     from rmr_amd.synthetic import image_features, pair_batch
     arch = rmr_amd.make_arch(dict(cross_encoder_num_hidden_layers=1, cross_encoder_max_position_embeddings=750, loss_fn="BCE"),
-                             has_vision=int(vision), compute_dtype="fp16")
+                             has_vision=int(vision), compute_dtype=dt)
     eng = rmr_amd.RerankEngine(arch)
     eng.load_state_dict(rmr_amd.synthetic_state_dict(arch, 0, True))
     Bq, K, S = 8, 100, 512
@@ -153,7 +153,7 @@ def test_packed_forward_at_the_bench_size(vision):
     assert torch.equal(got["logits"], again["logits"])
     assert not eng.activation_range_exceeded()           # the fp16 range guard stays quiet on the bench's weights
     d = (got["logits"] - ref["logits"]).abs().max().item()
-    record_margin(f"packed_c3_{'vision' if vision else 'text'}/fp16", packed_vs_padded=d, packed_rows=int(got["packed_rows"]), padded_rows=Bq * K * S)
+    record_margin(f"packed_c3_{'vision' if vision else 'text'}/{dt}", packed_vs_padded=d, packed_rows=int(got["packed_rows"]), padded_rows=Bq * K * S)
     if vision:      # measured 1.3e-4: the per-pair vision GEMMs run other tile shapes than the per-query ones, a 16-bit rounding flips
         assert d < 5e-4         # here and there (the fp16 forward itself sits 3.2e-4 from fp32 at this size)
     else:
