@@ -366,6 +366,9 @@ def main():
                        "fp16": "|logit - fp32 stock-HF| <= 1e-3 on every golden (compute_dtype=fp16; throughput below)",
                        "mode_meeting_1e-3_vs_fp32": "fp16", "this_line": args.compute_dtype},
             "gflop_per_pair": fpp / 1e9,
+            "gflop_per_pair_note": "SURVEY.md 8d: the REFERENCE's algorithmic FLOPs (every row of every layer); the library computes the "
+                                   "cross-encoder's last layer behind its K/V projection for the CLS rows only, so whole_path_* below are "
+                                   "reference-equivalent rates, not executed FLOPs (roofline.achieved counts executed FLOPs per launch)",
             "whole_path_tflops_per_gpu": pairs_per_s * fpp / 1e12 / world,
             "whole_path_frac_of_bf16_peak": pairs_per_s * fpp / 1e12 / world / PEAK_BF16_TFLOPS,
         }
@@ -422,6 +425,23 @@ def main():
                                               "window": "pinned host ids/masks/features -> HBM, rr_forward (K pairs, device-side "
                                                         "stable top-K), logits + order -> host; the reference's 'Rerank time' "
                                                         "window (1.40 s per query published for monoPreFLMR-B on its GPU)"}
+        if world == 1 and not args.no_alt_dtype and not args.bucketed and not args.packed:
+            # The library computes the cross-encoder's last layer behind its K / V projection for the CLS rows only (the classifiers
+            # read hidden state [:, 0]; same logits up to rounding).  The same step with every row of that layer computed, as the
+            # reference does, is reported beside the headline (rr_set_tuning "ce_cls_only" 0).
+            assert eng.lib.rr_set_tuning(b"ce_cls_only", 0) == 0
+            try:
+                for _ in range(max(1, args.warmup)):
+                    eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
+                torch.cuda.synchronize(dev)
+                res["all_cross_encoder_rows_mode"] = {"value": N * args.steps / (time.perf_counter() - t1), "unit": "pairs/s",
+                                                      "note": "the last cross-encoder layer computed for all rows (rr_set_tuning ce_cls_only 0)"}
+            finally:
+                eng.lib.rr_set_tuning(b"ce_cls_only", 1)
         if world == 1 and not args.no_alt_dtype and not args.fp8:
             # the same kernels with the other 16-bit operand type
             alt = "bf16" if args.compute_dtype == "fp16" else "fp16"

@@ -178,6 +178,7 @@ struct rr_model {
   // workspace (grow-only)
   char* ws = nullptr;
   size_t ws_cap = 0;
+  const float* cls_rows = nullptr;     // set by run_cross_encoder when its last layer ran on the CLS rows only: [n, Hc] fp32 (else null)
   int* range_flag = nullptr;           // device word raised by ln_finalize when a residual row nears the fp16 range (rr_activation_range_flag)
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
   bool pinned_blocks = false;          // rr_reserve was called or a stream capture was seen: outgrown blocks are retired, not freed
@@ -723,6 +724,7 @@ struct ResidSrc {
   RR_RUN(m, st, RR_K_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K, 2.0) + 8.0 * (M),                              \
          rr_launch_gemm_fold(A, lda, Wf, K, dvec, nullptr, 0, nullptr, nullptr, nullptr, fold, C, ldc, M, N, K, epi, m->dt, st))
 
+int g_ce_cls_only = 1;                   // tuning (rr_set_tuning "ce_cls_only"): 1 = the cross-encoder's last layer computes the CLS rows only
 int g_fp8_ffn_down = 1;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too
 constexpr float FP8_GELU_MUL = 8.0f;     // static scale of the e4m3 GELU output feeding it
 int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
@@ -923,10 +925,16 @@ int run_heads(rr_model* m, hipStream_t st, Work& w, const std::vector<Seg>& segs
               int32_t* order_out, bool logits_as_targets = false) {
   const rr_config& c = m->cfg;
   const int Hc = c.ce_hidden, N = Bq * K;
-  for (const Seg& g : segs) {
+  std::vector<Seg> one;
+  if (m->cls_rows) {      // the cross-encoder's last layer ran on the CLS rows only (run_cross_encoder): n contiguous rows
+    int n = 0;
+    for (const Seg& g : segs) n += g.n;
+    one.push_back(Seg{n, 1, 1, 0, 0, 0});
+  }
+  for (const Seg& g : (m->cls_rows ? one : segs)) {
     float* out_a = logits_out + pair_begin + g.p0;
     float* out_b = (logits2_out ? logits2_out + pair_begin : w.l2) + g.p0;
-    const float* h = w.h32 + g.rt0 * Hc;
+    const float* h = m->cls_rows ? m->cls_rows : w.h32 + g.rt0 * Hc;
     if (c.loss_kind == RR_LOSS_2H_BCE) {
       RR_RUN(m, st, RR_K_HEAD, 4.0 * g.n * Hc, 8.0 * g.n * Hc,
              rr_launch_cls_heads(h, g.T, Hc, g.n, m->cls2_w, m->cls2_b, m->cls1_w, m->cls1_b, out_a, out_b, st));
@@ -967,6 +975,51 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
     view.push_back(SegView{g.n, g.T, g.rt0});
   }
   const bool packed = segs.size() > 1;
+  m->cls_rows = nullptr;
+  if (g_ce_cls_only && !m->debug && !adj && c.ce_layers == 1) {
+    // Only the CLS row of every pair leaves the cross-encoder (the classifiers read hidden state [:, 0], utils.py:105-108):
+    // in its LAST layer every row is needed as a key and a value, but queries, attention output, both LayerNorms and the
+    // FFN only for that one row.  With one layer (every reference config: cross_encoder_num_hidden_layers = 1) the input is
+    // the materialised embedding LayerNorm output, so: K / V projection over all rows, then n-row launches for the rest.
+    // The reference computes all T rows and drops T - 1 of them; the taps (rr_set_debug) keep the full layer.
+    const LayerW& L = m->ce_layers[0];
+    const int heads = c.ce_heads;
+    Bump b((char*)w.mid);                     // FFN intermediate of the encoder stacks: free here
+    bf16_t* x16 = b.take<bf16_t>((size_t)n * Hc);
+    float* x32 = b.take<float>((size_t)n * Hc);
+    bf16_t* q16 = b.take<bf16_t>((size_t)n * Hc);
+    bf16_t* ctx16 = b.take<bf16_t>((size_t)n * Hc);
+    float* pre_a = b.take<float>((size_t)n * Hc);
+    float* a32 = b.take<float>((size_t)n * Hc);
+    bf16_t* a16 = b.take<bf16_t>((size_t)n * Hc);
+    bf16_t* mid16 = b.take<bf16_t>((size_t)n * Ic);
+    float* pre_b = b.take<float>((size_t)n * Hc);
+    float* out32 = b.take<float>((size_t)n * Hc);
+    bf16_t* out16 = b.take<bf16_t>((size_t)n * Hc);
+    RR_GEMM(m, st, w.h16, Hc, L.wqkv + (size_t)Hc * Hc, L.bqkv + Hc, nullptr, 0, w.qkv + Hc, 3 * Hc, RT, 2 * Hc, Hc, EPI_BIAS_BF16, 2.0);
+    for (const Seg& g : segs) {
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 12.0 * g.n * Hc,
+             rr_launch_gather_rows(w.h16 + g.rt0 * Hc, x16 + g.p0 * Hc, g.n, 1, g.T, Hc * 2, 0, 1, 0, st));
+      RR_RUN(m, st, RR_K_TAIL, 0.0, 12.0 * g.n * Hc,
+             rr_launch_gather_rows(w.h32 + g.rt0 * Hc, x32 + g.p0 * Hc, g.n, 1, g.T, Hc * 4, 0, 1, 0, st));
+    }
+    RR_GEMM(m, st, x16, Hc, L.wqkv, L.bqkv, nullptr, 0, q16, Hc, n, Hc, Hc, EPI_BIAS_BF16, 2.0);
+    for (const Seg& g : segs) {
+      const bf16_t* kv = w.qkv + g.rt0 * 3 * Hc;
+      RR_RUN(m, st, RR_K_ATTENTION, 4.0 * g.n * (double)g.T * Hc, 2.0 * 2.0 * g.n * g.T * Hc,
+             rr_launch_attention(q16 + g.p0 * Hc, Hc, 1, 0, kv + Hc, kv + 2 * Hc, 3 * Hc, w.ce_bias + g.rt0, g.n, heads, 1, g.T,
+                                 ctx16 + g.p0 * Hc, Hc, m->dt, st, nullptr, 0, (((long)n * heads + 7) / 8) * 8));   // (the one-segment call's schedule)
+    }
+    RR_GEMM(m, st, ctx16, Hc, L.wo, L.bo, x32, Hc, pre_a, Hc, n, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * Hc, rr_launch_layernorm(pre_a, L.ln1g, L.ln1b, c.ln_eps, n, Hc, a32, a16, m->dt, st));
+    RR_GEMM(m, st, a16, Hc, L.w1, L.b1, nullptr, 0, mid16, Ic, n, Ic, Hc, EPI_BIAS_GELU_BF16, 2.0);
+    RR_GEMM(m, st, mid16, Ic, L.w2, L.b2, a32, Hc, pre_b, Hc, n, Hc, Ic, EPI_BIAS_RESID_F32, 4.0);
+    RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * Hc, rr_launch_layernorm(pre_b, L.ln2g, L.ln2b, c.ln_eps, n, Hc, out32, out16, m->dt, st));
+    m->cls_rows = out32;
+    m->tap_ce = nullptr;
+    m->tap_ce_elems = 0;
+    return RR_OK;
+  }
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};
     int folded = OP_NORMALISED;
@@ -1793,6 +1846,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "fp8_ffn_down")) { g_fp8_ffn_down = value != 0; return RR_OK; }
+  if (!strcmp(key, "ce_cls_only")) { g_ce_cls_only = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
