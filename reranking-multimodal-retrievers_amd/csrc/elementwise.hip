@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, int rows, int T,
                                                           int cols, float* __restrict__ o32, bf16_t* __restrict__ o16,
-                                                          int dt, int s_text, int vis_pos0) {
+                                                          int dt, int s_text, int vis_pos0, int cls32) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const float* __restric
     }
   }
   const RowStats st = row_stats(v, n4, lane, cols, eps);
-  ln_store(v, st, gamma, beta, n4, lane, o32 + (size_t)row * cols, o16 + (size_t)row * cols, dt);
+  // cls32: the fp32 rows are wanted for the CLS row of each pair only (the cross-encoder's last layer on the CLS rows)
+  ln_store(v, st, gamma, beta, n4, lane, (cls32 && t != 0) ? nullptr : o32 + (size_t)row * cols, o16 + (size_t)row * cols, dt);
 }
 
 // ---- late-interaction rows: (x * mask) -> L2 normalise (F.normalize eps 1e-12) -> bf16, scattered
@@ -551,11 +552,11 @@ hipError_t rr_launch_embed_ln(const int64_t* ids, const int64_t* tts, const floa
 
 hipError_t rr_launch_ce_embed_ln(const float* x, const float* pos, const float* type0, const float* gamma,
                                  const float* beta, float eps, int rows, int T, int cols, float* o32, bf16_t* o16,
-                                 int dt, hipStream_t st, int s_text, int vis_pos0) {
+                                 int dt, hipStream_t st, int s_text, int vis_pos0, int cls32_only) {
   if (rows <= 0 || (cols & 3) || cols > 64 * 4 * MAX_V4) return hipErrorInvalidValue;
   if (s_text < 0 || s_text > T) { s_text = T; vis_pos0 = T; }     // plain positions 0 .. T-1
   hipLaunchKernelGGL(ce_embed_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, pos, type0, gamma, beta, eps,
-                     rows, T, cols, o32, o16, dt, s_text, vis_pos0);
+                     rows, T, cols, o32, o16, dt, s_text, vis_pos0, cls32_only);
   return hipGetLastError();
 }
 

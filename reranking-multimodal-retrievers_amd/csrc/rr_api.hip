@@ -21,7 +21,7 @@
 hipError_t rr_launch_embed_ln(const int64_t*, const int64_t*, const float*, const float*, const float*, const float*,
                               const float*, float, int, int, int, int, int, float*, bf16_t*, int, hipStream_t);
 hipError_t rr_launch_ce_embed_ln(const float*, const float*, const float*, const float*, const float*, float, int, int,
-                                 int, float*, bf16_t*, int, hipStream_t, int s_text = -1, int vis_pos0 = 0);
+                                 int, float*, bf16_t*, int, hipStream_t, int s_text = -1, int vis_pos0 = 0, int cls32_only = 0);
 hipError_t rr_launch_li_normalize(const float*, const int64_t*, int, int, int, int, int, int, int, int, int, bf16_t*,
                                   int, int, const float*, int, int, hipStream_t);
 hipError_t rr_launch_joint_masks(const int64_t*, const int64_t*, int, int, int, int, long long, float*, float*, float*,
@@ -967,16 +967,17 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
   for (const Seg& g : segs) n += g.n;
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
   std::vector<SegView> view;
-  for (const Seg& g : segs) {
-    RR_RUN(m, st, RR_K_EMBED, 0.0, 14.0 * g.n * g.T * Hc,
+  const bool cls_only = g_ce_cls_only && !m->debug && !adj && c.ce_layers == 1;
+  for (const Seg& g : segs) {      // (cls_only: the fp32 copy of the embedding rows is the residual of the CLS rows only)
+    RR_RUN(m, st, RR_K_EMBED, 0.0, (cls_only ? 10.0 : 14.0) * g.n * g.T * Hc,
            rr_launch_ce_embed_ln(w.pre + g.rt0 * Hc, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, g.n * g.T, g.T, Hc,
                                  w.h32 + g.rt0 * Hc, w.h16 + g.rt0 * Hc, m->dt, st, vis_pos0 >= 0 ? g.S : -1,
-                                 vis_pos0 >= 0 ? vis_pos0 : 0));
+                                 vis_pos0 >= 0 ? vis_pos0 : 0, cls_only ? 1 : 0));
     view.push_back(SegView{g.n, g.T, g.rt0});
   }
   const bool packed = segs.size() > 1;
   m->cls_rows = nullptr;
-  if (g_ce_cls_only && !m->debug && !adj && c.ce_layers == 1) {
+  if (cls_only) {
     // Only the CLS row of every pair leaves the cross-encoder (the classifiers read hidden state [:, 0], utils.py:105-108):
     // in its LAST layer every row is needed as a key and a value, but queries, attention output, both LayerNorms and the
     // FFN only for that one row.  With one layer (every reference config: cross_encoder_num_hidden_layers = 1) the input is
