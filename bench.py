@@ -357,6 +357,10 @@ def main():
                                        "1 RCCL all-gather of logits/step") if distributed else
                                       "1 GPU, no process group, no collective (the N > 1 legs shard the pairs over ranks with one "
                                       "RCCL all-gather of logits per step)",
+                       "cross_encoder_last_layer": "all layers run; in the cross-encoder's (single, last) layer K/V are projected for every row and the "
+                                                   "query / attention-output / LayerNorm / FFN work is done for the CLS row of each pair only - "
+                                                   "the only row the classifiers read (utils.py:105-108); logits equal the all-rows computation up "
+                                                   "to rounding; all_cross_encoder_rows_mode = the same step with every row computed",
                        "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"
                                   + (f"; Linear matrices widened x{args.weights_gain} (peaked attention)" if args.weights_gain != 1.0 else "")},
             "step_ms_device": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
