@@ -527,6 +527,39 @@ def test_length_bucketed_forward_equals_the_padded_forward(name):
     assert torch.equal(again["logits"], ref["logits"])
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_mm", "tiny_2h", "c2", "c3s"])
+def test_cls_only_cross_encoder_layer_equals_the_all_rows_layer(name):
+    """The cross-encoder's last layer behind its K / V projection runs for the CLS row of every pair only (rr_api.hip
+    run_cross_encoder: the classifiers read hidden state [:, 0], utils.py:105-108).  Against the same layer computed for
+    every row (rr_set_tuning "ce_cls_only" 0; also what the debug taps use): the same logits up to re-decided 16-bit
+    roundings, and both within north_star's 1e-3 of the fp32 stock-HF golden (fp16 operands)."""
+    from rmr_amd import _lib
+    lib = _lib.load()
+    g = load_golden(name)
+    cfg, vision = g["cfg"], g["vision"]
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    eng = _engine(cfg, vision, w, "fp16")
+    ids, am, tt, img = golden_inputs(g)
+    lab = torch.tensor(g["labels_list"]).cuda() if g["labels_list"] is not None else None
+    args = (ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], img[0].cuda() if vision else None, img[1].cuda() if vision else None, lab)
+    cls_only = eng.forward_ids(*args, want_order=True)
+    try:
+        assert lib.rr_set_tuning(b"ce_cls_only", 0) == 0
+        all_rows = eng.forward_ids(*args, want_order=True)
+    finally:
+        lib.rr_set_tuning(b"ce_cls_only", 1)
+    torch.cuda.synchronize()
+    gold = torch.from_numpy(g["logits"]).reshape(-1)
+    a, b = cls_only["logits"].cpu(), all_rows["logits"].cpu()
+    d_ab, d_a, d_b = (a - b).abs().max().item(), (a - gold).abs().max().item(), (b - gold).abs().max().item()
+    print(f"[{name}/fp16] CLS-only vs all rows {d_ab:.2e}; vs fp32 golden: CLS-only {d_a:.2e}, all rows {d_b:.2e}")
+    record_margin(f"{name}/fp16/cls_only_layer", cls_only_vs_all_rows=d_ab, cls_only_vs_golden=d_a, all_rows_vs_golden=d_b)
+    assert d_ab <= 5e-4 and d_a <= 1e-3 and d_b <= 1e-3
+    assert abs(cls_only["loss"].item() - all_rows["loss"].item()) < 1e-4
+    if cfg.loss_fn == "2H_BCE":
+        assert (cls_only["logits2"] - all_rows["logits2"]).abs().max().item() <= 5e-4
+
+
 @pytest.mark.parametrize("name", ["c2", "tiny_mm", "tiny_2h"])
 def test_packed_forward_equals_the_bucketed_and_the_padded_forward(name):
     """RerankEngine.forward_ids_packed (rr_forward_packed): the pairs laid out group after group at their group's row length,
