@@ -77,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--bucketed", action="store_true",
                     help="length-bucketed execution (RerankEngine.forward_ids_bucketed): with --regime realistic the pairs run at the "
                          "row length of their bucket instead of the padded seq_len; pairs/s still counts padded pairs (the contract)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: capture the step into a HIP graph (the library is capturable after rr_reserve) and time replays; "
+                         "profiling events are off in this mode (the line carries no live roofline)")
     ap.add_argument("--packed", action="store_true",
                     help="packed execution (RerankEngine.forward_ids_packed / rr_forward_packed): the pairs grouped by length in steps "
                          "of --granule rows, every GEMM of a layer ONE launch over the rows that exist; pairs/s still counts padded pairs")
@@ -300,6 +303,26 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.graph:
+        assert not distributed and not args.bucketed and not args.packed, "--graph: plain single-process step only"
+        args.no_profile = True
+        gst = torch.cuda.Stream()
+        with torch.cuda.stream(gst):
+            eng.reserve(N + 1, Bq, S)                  # the redo-flag buffer is per stream
+            step()                                     # function attributes etc. on the capture stream
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=gst):
+                gout = step()
+        eager_step = step
+
+        def step():                                    # noqa: F811 — replay on the current stream
+            graph.replay()
+            return gout
+        ref = eager_step()
+        step()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(ref["logits"], gout["logits"]), "graph replay differs from the eager step"
     redo = None
     if args.weights_gain != 1.0:      # one untimed step with the redo counters on: how often the fixed-reference attention falls back
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -361,6 +384,7 @@ def main():
                                                    "query / attention-output / LayerNorm / FFN work is done for the CLS row of each pair only - "
                                                    "the only row the classifiers read (utils.py:105-108); logits equal the all-rows computation up "
                                                    "to rounding; all_cross_encoder_rows_mode = the same step with every row computed",
+                       **({"launch": "the step is ONE captured HIP graph, replayed"} if args.graph else {}),
                        "weights": "seeded random init (HF init), fp32 master -> 16-bit MFMA operands"
                                   + (f"; Linear matrices widened x{args.weights_gain} (peaked attention)" if args.weights_gain != 1.0 else "")},
             "step_ms_device": {"median": pct(step_ms, 0.5), "p10": pct(step_ms, 0.1), "p90": pct(step_ms, 0.9),
