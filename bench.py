@@ -279,7 +279,7 @@ def main():
     if vision:
         cls, pat = image_features(Bq, arch["n_patches"], arch["vision_hidden"])
         cls, pat = cls.to(dev), pat.to(dev)
-    eng.reserve(-(-N // world) + 1, Bq, S)                   # no allocation / synchronisation inside the steps
+    eng.reserve(-(-N // world) + 1, Bq, S, packed=bool(args.packed or args.bucketed))   # no allocation / synchronisation inside the steps
 
     host_lengths = None
     if args.packed:

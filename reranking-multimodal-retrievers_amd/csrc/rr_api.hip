@@ -181,7 +181,7 @@ struct rr_model {
   const float* cls_rows = nullptr;     // set by run_cross_encoder when its last layer ran on the CLS rows only: [n, Hc] fp32 (else null)
   int* range_flag = nullptr;           // device word raised by ln_finalize when a residual row nears the fp16 range (rr_activation_range_flag)
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
-  bool pinned_blocks = false;          // rr_reserve was called or a stream capture was seen: outgrown blocks are retired, not freed
+  bool pinned_blocks = false;          // a stream capture was seen on this handle: outgrown blocks are retired, not freed
   std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
 
   // last-forward taps
@@ -557,6 +557,7 @@ struct Bump {
 struct Work {
   float *h32, *pre, *pre2, *stats_a, *stats_b, *li32, *text_bias, *ce_bias, *l1, *l2, *part_l, *part_w, *li_mask, *lnpart, *rowscale;
   bf16_t *h16, *qkv, *ctx, *mid, *li16;
+  char* cls_scratch;                   // the CLS-only cross-encoder layer's n-row buffers (run_cross_encoder)
   // vision
   bf16_t *cls16, *vp_mid16, *pat16, *t16, *vqkv, *vctx, *a16, *q_c, *enc16, *kv_c, *cctx, *c16, *vmid, *m16;
   float *vp_out32, *t32, *vpre, *a32, *a32b, *cpre, *c32, *m32, *mo32;
@@ -583,6 +584,11 @@ size_t layout_vit(const rr_config& c, int kp, int B, char* base, VitWork* w) {
 
 size_t imax(size_t a, size_t b) { return a > b ? a : b; }
 
+// n-row buffers of the CLS-only cross-encoder layer (run_cross_encoder): 11 regions, 30 Hc + 2 Ic bytes per pair plus the
+// 256-byte alignment of each.  A region of its own (carved out of w.mid they overran it for rows shorter than ~6).
+size_t cls_scratch_bytes(const rr_config& c, int n) {
+  return (size_t)n * (30 * (size_t)c.ce_hidden + 2 * (size_t)c.ce_intermediate) + 11 * 256;
+}
 // Lays out the workspace for n local pairs of (at most) Bq queries; base == nullptr => size query.
 size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base, Work* w) {
   Bump b(base);
@@ -609,6 +615,7 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
   w->l2 = b.take<float>(n);
   w->part_l = b.take<float>(Bq);
   w->part_w = b.take<float>(Bq);
+  w->cls_scratch = b.take<char>(cls_scratch_bytes(c, n));
   if (vision) {
     const size_t Hh = c.hidden, np = c.n_patches, Vh = c.vision_hidden, D = c.li_dim, PL = c.prefix_len;
     const size_t ca = (size_t)(S < c.cross_attn_len ? S : c.cross_attn_len);
@@ -642,7 +649,7 @@ size_t layout(const rr_config& c, int n, int Bq, int S, bool vision, char* base,
 
 // Growth outside rr_reserve synchronises the stream and replaces the old block: legal on a plain stream, not while the
 // stream is being captured into a graph -> refused there.  A graph captured EARLIER holds the old block's address in its
-// kernel nodes: once rr_reserve has been called or a capture has been seen on this handle (pinned_blocks), an outgrown
+// kernel nodes: once a capture has been SEEN on this handle (pinned_blocks; every forward looks), an outgrown
 // block is not freed but retired until rr_destroy, so that replaying such a graph after a later, larger forward stays
 // valid (it computes in the old block).
 int capture_guard(rr_model* m, hipStream_t st, const char* what) {
@@ -693,6 +700,7 @@ extern "C" int rr_set_resid_touch(int on);
 extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 extern "C" int rr_set_resid_fast(int on);
+extern "C" int rr_set_gemm_direct(int on);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
@@ -985,7 +993,7 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
     // The reference computes all T rows and drops T - 1 of them; the taps (rr_set_debug) keep the full layer.
     const LayerW& L = m->ce_layers[0];
     const int heads = c.ce_heads;
-    Bump b((char*)w.mid);                     // FFN intermediate of the encoder stacks: free here
+    Bump b(w.cls_scratch);
     bf16_t* x16 = b.take<bf16_t>((size_t)n * Hc);
     float* x32 = b.take<float>((size_t)n * Hc);
     bf16_t* q16 = b.take<bf16_t>((size_t)n * Hc);
@@ -997,6 +1005,7 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
     float* pre_b = b.take<float>((size_t)n * Hc);
     float* out32 = b.take<float>((size_t)n * Hc);
     bf16_t* out16 = b.take<bf16_t>((size_t)n * Hc);
+    if (b.off > cls_scratch_bytes(c, n)) return fail(m, RR_ERR_BAD_ARG, "internal: CLS-only scratch %zu > %zu bytes", b.off, cls_scratch_bytes(c, n));
     RR_GEMM(m, st, w.h16, Hc, L.wqkv + (size_t)Hc * Hc, L.bqkv + Hc, nullptr, 0, w.qkv + Hc, 3 * Hc, RT, 2 * Hc, Hc, EPI_BIAS_BF16, 2.0);
     for (const Seg& g : segs) {
       RR_RUN(m, st, RR_K_TAIL, 0.0, 12.0 * g.n * Hc,
@@ -1059,6 +1068,7 @@ size_t layout_interaction(const rr_config& c, int n, int Bq, int Lq, int Lc, cha
   w->l2 = b.take<float>(n);
   w->part_l = b.take<float>(Bq);
   w->part_w = b.take<float>(Bq);
+  w->cls_scratch = b.take<char>(cls_scratch_bytes(c, n));   // (an interaction reranker with ONE cross-encoder layer takes the CLS-only path too)
   if (c.model_kind == RR_MODEL_MORES) {
     w->a32 = b.take<float>((size_t)n * Lq * Hc);
     w->a16 = b.take<bf16_t>((size_t)n * Lq * Hc);
@@ -1203,11 +1213,11 @@ static int rr_finalize_weights_impl(rr_handle h) {
     if (!h->host.count(n)) return fail(h, RR_ERR_MISSING_WEIGHT, "missing weight: %s", n.c_str());
   rr_model* m = h;
   const rr_config& c = m->cfg;
+  RR_HIP(m, hipSetDevice(c.device));       // before ANY allocation: the engine's device need not be the current one
   if (!m->range_flag) {
     RR_TRY(dev_alloc(m, (void**)&m->range_flag, sizeof(int)));
     RR_HIP(m, hipMemset(m->range_flag, 0, sizeof(int)));
   }
-  RR_HIP(m, hipSetDevice(c.device));
   if (c.model_kind != RR_MODEL_FULL_CONTEXT) {
     RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
     RR_TRY(up_f32(m, HT(m, "cross_encoder_input_mapping.bias"), &m->b_cemap));
@@ -1309,7 +1319,6 @@ static int rr_reserve_impl(rr_handle h, int n_pairs, int n_queries, int len_a, i
     T = len_a + len_b;
   }
   RR_HIP(m, rr_attention_reserve(n_pairs, c.ce_heads, T, st));
-  m->pinned_blocks = true;               // from here on outgrown blocks are retired, not freed (a graph may hold their addresses)
   RR_TRY(ensure_ws(m, need, st));
   if (with_fusion) RR_TRY(ensure_adj(m, (size_t)n_pairs * T * ((T + 63) / 64 * 64) * sizeof(float), st));
   return RR_OK;
@@ -1418,6 +1427,11 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     if (S > m->padded_S) return fail(m, RR_ERR_BAD_SHAPE, "seq_len %d exceeds the padded length %d set by rr_set_padded_seq_len", S, m->padded_S);
     if (m->padded_S + P > c.ce_max_pos)
       return fail(m, RR_ERR_BAD_SHAPE, "padded cross-encoder length %d exceeds cross_encoder_max_position_embeddings %d", m->padded_S + P, c.ce_max_pos);
+    // the mapping network's cross-attention reads the first cross_attn_len text rows of a pair: a bucket shorter than that
+    // would read fewer rows than the padded call does (rr_forward_packed refuses the same case)
+    if (vision && S < (m->padded_S < c.cross_attn_len ? m->padded_S : c.cross_attn_len))
+      return fail(m, RR_ERR_BAD_SHAPE, "bucketed seq_len %d is below the %d text rows the vision mapping network attends to", S,
+                  m->padded_S < c.cross_attn_len ? m->padded_S : c.cross_attn_len);
     vis_pos0 = m->padded_S;
   }
   if (packed) {
@@ -1852,6 +1866,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "resid_fast")) return rr_set_resid_fast(value);
+  if (!strcmp(key, "gemm_direct")) return rr_set_gemm_direct(value);
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);

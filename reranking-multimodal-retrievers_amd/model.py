@@ -324,7 +324,10 @@ class RerankEngine:
         cols = torch.arange(1, S + 1, device=dev)
         used = (input_ids != 0) | (attention_mask != 0)
         lens = (used * cols).amax(1)                                   # 1 + index of the last non-pad position
-        sizes = sorted({int(b) for b in buckets if 0 < int(b) < S}) + [S]
+        # with vision tokens the mapping network attends to the first cross_attn_len text rows: no bucket below that (the
+        # library refuses it: RR_ERR_BAD_SHAPE)
+        floor = min(S, int(self.arch.get("cross_attn_len", 32))) if image_cls is not None else 1
+        sizes = sorted({max(int(b), floor) for b in buckets if 0 < int(b) < S and max(int(b), floor) < S}) + [S]
         which = torch.bucketize(lens, torch.tensor(sizes, device=dev))  # smallest bucket with size >= len
         counts = torch.bincount(which, minlength=len(sizes)).cpu().tolist()
         logits = torch.empty(N, dtype=torch.float32, device=dev)
@@ -558,9 +561,14 @@ class RerankEngine:
     def workspace_bytes(self, n_pairs: int, S: int) -> int:
         return int(self.lib.rr_workspace_bytes(self.h, n_pairs, S))
 
-    def reserve(self, n_pairs: int, n_queries: int, len_a: int, len_b: int = 0, with_fusion: bool = False):
+    def reserve(self, n_pairs: int, n_queries: int, len_a: int, len_b: int = 0, with_fusion: bool = False,
+                packed: bool = False):
         """Allocate everything a forward of at most this shape needs (rr_reserve) on the current stream: afterwards the
-        forward neither allocates nor synchronises (a precondition for capturing it into a hipGraph)."""
+        forward neither allocates nor synchronises (a precondition for capturing it into a hipGraph).  `packed`: for
+        forward_ids_packed / forward_ids_bucketed, whose image features are per PAIR (n_queries = n_pairs, as
+        include/rerank_mi355.h documents for rr_forward_packed)."""
+        if packed:
+            n_queries = n_pairs
         L.check(self.lib.rr_reserve(self.h, int(n_pairs), int(n_queries), int(len_a), int(len_b), int(with_fusion),
                                     torch.cuda.current_stream(self.device).cuda_stream), self.h, "rr_reserve")
 

@@ -560,6 +560,65 @@ def test_cls_only_cross_encoder_layer_equals_the_all_rows_layer(name):
         assert (cls_only["logits2"] - all_rows["logits2"]).abs().max().item() <= 5e-4
 
 
+@pytest.mark.parametrize("S,n", [(4, 1), (3, 1), (2, 3), (6, 2)])
+def test_cls_only_layer_on_very_short_rows(S, n):
+    """the CLS-only layer's eleven n-row buffers were carved out of the FFN intermediate (n * T * I * 2 bytes) with no
+    capacity check: for rows of <= 5-6 tokens they overran it (for S <= 3 past the end of the workspace).  They are a workspace
+    region of their own now (rr_workspace_bytes covers it).  Text-only tiny model at S = 2..6, one to three pairs: finite
+    logits, equal to the all-rows layer up to re-decided roundings, and intact neighbours (a second, longer forward on the same
+    handle still reproduces its own result)."""
+    from rmr_amd import _lib
+    lib = _lib.load()
+    g = load_golden("tiny")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=False)
+    eng = _engine(cfg, False, w, "fp16")
+    ids, am, tt = O.make_pair_batch(cfg, n, 1, S, seed=3)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), n, 1, None, None, None)
+    a = eng.forward_ids(*args)
+    try:
+        assert lib.rr_set_tuning(b"ce_cls_only", 0) == 0
+        b = eng.forward_ids(*args)
+    finally:
+        lib.rr_set_tuning(b"ce_cls_only", 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a["logits"]).all() and torch.isfinite(b["logits"]).all()
+    assert (a["logits"] - b["logits"]).abs().max().item() <= 5e-4
+    with torch.no_grad(), O.device_rounding(torch.float16) as mm:
+        ref = O.full_context_forward(cfg, w, ids, am, tt, n, 1, None, None, mm=mm)
+    assert (a["logits"].cpu().view(-1) - ref.logits.view(-1)).abs().max().item() <= 1e-3
+
+
+def test_bucket_below_the_vision_window_is_refused_and_clamped():
+    """with image features the mapping network's cross-attention reads the first cross_attn_len text rows of a pair.
+    A bucketed forward at a row length below that (rr_set_padded_seq_len + a shorter rr_forward) silently read fewer rows than
+    the padded call; the library now refuses it (RR_ERR_BAD_SHAPE -> AssertionError like the reference's shape asserts) and
+    forward_ids_bucketed clamps its bucket sizes, so a user bucket of 8 gives the padded forward's logits."""
+    g = load_golden("tiny_mm")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=True)
+    eng = _engine(cfg, True, w, "fp16")
+    ids, am, tt, img = golden_inputs(g)
+    S = ids.shape[1]
+    assert cfg.cross_attn_len < S
+    short = max(2, cfg.cross_attn_len // 2)
+    ids2 = ids.clone(); am2 = am.clone()
+    ids2[:, short - 1:] = 0; am2[:, short - 1:] = 0                      # every pair fits the short bucket
+    args = (ids2.cuda(), am2.cuda(), tt.cuda(), g["Bq"], g["K"], img[0].cuda(), img[1].cuda(), None)
+    padded = eng.forward_ids(*args)
+    bucketed = eng.forward_ids_bucketed(*args, buckets=(short,))
+    torch.cuda.synchronize()
+    assert (padded["logits"] - bucketed["logits"]).abs().max().item() <= 5e-5
+    from rmr_amd import _lib as L
+    L.check(eng.lib.rr_set_padded_seq_len(eng.h, S), eng.h, "rr_set_padded_seq_len")
+    try:
+        with pytest.raises((AssertionError, ValueError, RuntimeError)):
+            eng.forward_ids(ids2[:, :short].contiguous().cuda(), am2[:, :short].contiguous().cuda(), tt[:, :short].contiguous().cuda(),
+                            g["Bq"], g["K"], img[0].cuda(), img[1].cuda(), None)
+    finally:
+        L.check(eng.lib.rr_set_padded_seq_len(eng.h, 0), eng.h, "rr_set_padded_seq_len")
+
+
 @pytest.mark.parametrize("name", ["c2", "tiny_mm", "tiny_2h"])
 def test_packed_forward_equals_the_bucketed_and_the_padded_forward(name):
     """RerankEngine.forward_ids_packed (rr_forward_packed): the pairs laid out group after group at their group's row length,
