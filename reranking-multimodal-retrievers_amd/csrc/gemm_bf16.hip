@@ -2018,7 +2018,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
 
 // persistent ring with the direct epilogue (variant 16; the default for the 16-bit output forms of large problems,
 // rr_set_tuning "gemm_direct"): same grid and LDS as launch_hp
-std::atomic<int> g_direct{1};
+std::atomic<int> g_direct{0};     // measured slower than the staged epilogue (profiles/r04_a_*): off
 inline bool hq_eligible(int M, int N, int Kd, int epilogue, const LnResid& ln) {
   if (epilogue != EPI_BIAS_BF16 && epilogue != EPI_BIAS_GELU_BF16) return false;
   if (ln.x16 || ln.r_hi || ln.lo_out || ln.stats) return false;

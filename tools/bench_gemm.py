@@ -19,6 +19,8 @@ ap.add_argument("--variants", default="2,10,12,14")
 ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--stagger", default="0")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--same-rows", default="", help="a / w / aw: every row of A and / or W holds the SAME random values (full memory traffic, "
+                "little operand toggling): separates what operand data costs from what operand traffic costs (cf. --stagger 63 / 62)")
 ap.add_argument("--timeline", action="store_true", help="variant 13: per-wave phase timeline of the ring kernel (qkv shape)")
 a = ap.parse_args()
 lib = _lib.load()
@@ -57,6 +59,10 @@ if a.timeline:
 for name, N, K, epi in shapes:
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
     W = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
+    if "a" in a.same_rows:
+        A = A[:1].expand(M, K).contiguous()
+    if "w" in a.same_rows:
+        W = W[:1].expand(N, K).contiguous()
     b = torch.randn(N, generator=g).cuda()
     R = torch.randn(M, N, device="cuda") if epi == 4 else None
     out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == 4 else torch.bfloat16)
