@@ -174,6 +174,28 @@ int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, in
  * Python: RerankEngine.forward_ids_bucketed. */
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
 
+/* Per-handle numerics options: everything that changes WHICH arithmetic a forward of this handle runs lives in the handle
+ * ("no global state => several handles per process"; the reference's analogue is the reranker_config each
+ * module instance owns, Reranker_base_executor.py:191-202).  Two handles of one process may differ in any of them; a change
+ * takes effect with the next forward of THAT handle.
+ *   key              values                 default   meaning
+ *   "ln_lite"        0 | 1                  1         1: residuals are recomputed from LayerNorm statistics; 0: every LayerNorm
+ *                                                     writes its fp32 output and the residual GEMMs read it back (reference dataflow)
+ *   "ln_fold"        0 | 1                  1         1: LayerNorm folded into the consumer GEMMs (QKV, FFN-up); 0: LayerNorm kernels
+ *   "resid_split"    0 | 1                  1         1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo
+ *                                                     (where the persistent ring runs); 0: fp32 rows
+ *   "ce_cls_only"    0 | 1                  1         1: the cross-encoder's last layer computes queries / FFN for the CLS row of a
+ *                                                     pair only (all the classifiers read, utils.py:105-108); 0: every row
+ *   "fp8_ffn_down"   0 | 1                  0         rr_config.fp8 only: FFN-down on the e4m3 ring too (GELU output as e4m3 under a
+ *                                                     static scale of 8); 0: FFN-down keeps 16-bit operands
+ *   "attn_fixed_ref" 0 | 1 | 2 | 3          3         softmax schedule of large attention grids: 0 online only, 1 fixed reference
+ *                                                     with 32 query rows per wave, 2 with 64, 3: 2 where 256-row workgroups pad no
+ *                                                     more rows than 128-row ones, else 1
+ * value -1 = "not set": the handle follows the process-wide diagnostic switch of the same name (rr_set_tuning), which is what
+ * every option starts as.  rr_get_option returns the EFFECTIVE value.  RR_ERR_BAD_ARG: unknown key, value out of range. */
+int rr_set_option(rr_handle h, const char* key, int value);
+int rr_get_option(rr_handle h, const char* key, int* value_out);
+
 /* Range guard of the 16-bit residual rows.  With the folded LayerNorm the RAW pre-LayerNorm rows are MFMA operands and the
  * `hi` half of the residual stream; fp16 (the mode that meets 1e-3) ends at 65 504.  The kernel that merges the rows'
  * LayerNorm statistics raises a device-side flag when a row's sum of squares reaches 9e8 (no element of a row below that can
@@ -400,7 +422,7 @@ int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* b
  * operand rounding (the consumer GEMM's A rows) + lo = fp16(x - hi) instead of a separate fp32 copy.  Residual rows come in as
  * (hi_in, lo_in) [M,N] — normalised on the fly with (ln_stats [M,2], ln_gamma, ln_beta) when ln_stats != NULL — and the output
  * rows x = A W^T + bias + residual leave as (x16_out, lo_out) plus their statistics; hi_in == x16_out and lo_in == lo_out
- * (in place) is allowed.  Only for shapes the persistent ring kernel runs (>= 512 tiles of 256 x 256, N % 8 == 0), otherwise
+ * (in place) is allowed.  Only for shapes the persistent ring kernel runs (>= 128 tiles of 256 x 256 — rr_set_tuning "gemm_ring_min_tiles" —, N % 8 == 0), otherwise
  * RR_ERR_UNSUPPORTED. */
 int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in, const uint16_t* lo_in,
                            const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
@@ -420,7 +442,14 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
                        float* row_scale, float* stats, void* hip_stream);
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host);
 int rr_set_gemm_variant(int variant);
-int rr_set_tuning(const char* key, int value);   /* process-wide A/B switches: "ln_lite" (default 1), "ln_fold" (default 1: LayerNorm folded into the consumer GEMMs; 0 = LayerNorm kernels), "resid_split" (default 1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo instead of fp32), "resid_touch" (default 0: L2 touch of the next residual pass; the rows themselves are requested a pass ahead), "gemm_desync" (default 0: diagnostic start skew of the XCDs, percent of a tile period), "persistent_gemm" (default 1), "attn_prio" (default 1), "attn_fixed_ref" (0 online softmax only, 1 fixed reference with 32 query rows per wave, 2 with 64, 3 = default: 2 where 256-row workgroups pad no more rows than 128-row ones, else 1; any other value restores the default) */
+/* Process-wide DIAGNOSTIC switches (A/B tools, tests): the default every handle option of the same name follows until
+ * rr_set_option pins it ("ln_lite", "ln_fold", "resid_split", "ce_cls_only", "fp8_ffn_down", "attn_fixed_ref": see rr_set_option),
+ * plus switches that select between bit-identical kernels or only move time: "resid_fast" (default 1: plain fp32 residual GEMMs
+ * on the split forms' epilogue), "resid_touch" (0: L2 touch of the next residual pass), "gemm_desync" (0: start skew of the XCDs,
+ * percent of a tile period), "persistent_gemm" (1), "gemm_direct" (0: 16-bit epilogues straight from the accumulators,
+ * gemm_kernel_hq — measured slower), "gemm_ring_min_tiles" (128: smallest problem, in 256 x 256 tiles, on the persistent ring),
+ * "attn_prio" (1).  Not thread-safe against running forwards; never needed on the product path. */
+int rr_set_tuning(const char* key, int value);
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */

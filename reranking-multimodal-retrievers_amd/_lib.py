@@ -59,6 +59,8 @@ _SIGS = {
     "rr_required_weight_name": (C.c_char_p, [_P, C.c_int]),
     "rr_workspace_bytes": (C.c_int64, [_P, C.c_int, C.c_int]),
     "rr_set_padded_seq_len": (C.c_int, [_P, C.c_int]),
+    "rr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "rr_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "rr_reserve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rr_activation_range_flag": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P]),
     "rr_forward_packed": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P]),

@@ -873,7 +873,9 @@ hipError_t rr_attention_reserve(int B, int heads, int Tq, hipStream_t st) {
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B, int heads,
                                int Tq, int Tk, bf16_t* out, int out_stride, int dt, hipStream_t st,
-                               const float* dense_bias, int dense_ld, long schedule_blocks) {
+                               const float* dense_bias, int dense_ld, long schedule_blocks, int fixed_mode) {
+  // fixed_mode: the caller's schedule choice (a handle's "attn_fixed_ref" option), < 0 = the process-wide switch
+  const int fixed_host = fixed_mode >= 0 && fixed_mode <= 3 ? fixed_mode : g_attn_fixed_host;
   // schedule_blocks > 0: the grid size that decides between the online and the fixed-reference schedule — a packed forward
   // (rr_forward_packed) launches one segment at a time and passes the PADDED call's grid, so that every pair runs the
   // schedule, hence the roundings, of the padded forward however few pairs share its length
@@ -889,12 +891,12 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
              dense_bias, dense_ld, nullptr, g_attn_prio_host, nullptr, (int)nblk, g_attn_redo_stats};
   const bool diag = g_attn_stamps && dt == 0 && !dense_bias;   // diagnostic timeline (tools/attn_timeline.py)
   if (diag) a.stamps = g_attn_stamps;
-  if (g_attn_fixed_host && !dense_bias && (schedule_blocks > 0 ? schedule_blocks : nblk) >= ATTN_FIXED_MIN_BLOCKS) {
+  if (fixed_host && !dense_bias && (schedule_blocks > 0 ? schedule_blocks : nblk) >= ATTN_FIXED_MIN_BLOCKS) {
     // 64 query rows per wave: 256-row workgroups, flags per 256-row workgroup.  Half the K/V fragment reads and DMA pieces
     // per query row (the launch is clock-limited by power: fewer LDS bytes per MFMA is what it answers to), at 2 waves per
     // SIMD; padding to 256 rows must not cost more than that saves.
-    const bool rows64 = g_attn_fixed_host == 2 || (g_attn_fixed_host == 3 && ((Tq + 255) / 256) * 2 == (Tq + 127) / 128);
-    if (rows64 && (!diag || g_attn_fixed_host == 2)) {     // (stamps + attn_fixed_ref 2: the 64-row form's own timeline)
+    const bool rows64 = fixed_host == 2 || (fixed_host == 3 && ((Tq + 255) / 256) * 2 == (Tq + 127) / 128);
+    if (rows64 && (!diag || fixed_host == 2)) {     // (stamps + attn_fixed_ref 2: the 64-row form's own timeline)
       const long nblk64 = ((groups + 7) / 8) * 8 * ((Tq + 255) / 256);
       a.nblk = (int)nblk64;
       hipError_t e = attn_flags(nblk64, st, &a.flags);
@@ -931,17 +933,18 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
 hipError_t rr_launch_attention_segs(const bf16_t* q, int q_stride, const bf16_t* k, const bf16_t* v, int kv_stride,
                                     const float* key_bias, int heads, int nseg, const int* seg_n, const int* seg_len,
                                     const long long* seg_row0, bf16_t* out, int out_stride, int dt, hipStream_t st,
-                                    long schedule_blocks) {
+                                    long schedule_blocks, int fixed_mode) {
+  const int fixed_host = fixed_mode >= 0 && fixed_mode <= 3 ? fixed_mode : g_attn_fixed_host;
   if (dt != 0 && dt != 1) return hipErrorInvalidValue;
   if (nseg <= 0 || heads <= 0 || !seg_n || !seg_len || !seg_row0) return hipErrorInvalidValue;
   if ((q_stride & 7) || (kv_stride & 7) || (out_stride & 7)) return hipErrorInvalidValue;
-  const bool one_launch = g_attn_fixed_host && schedule_blocks >= ATTN_FIXED_MIN_BLOCKS && nseg <= ATTN_MAX_SEGS && !g_attn_stamps;
+  const bool one_launch = fixed_host && schedule_blocks >= ATTN_FIXED_MIN_BLOCKS && nseg <= ATTN_MAX_SEGS && !g_attn_stamps;
   if (!one_launch) {
     for (int s = 0; s < nseg; ++s) {
       const bf16_t* q0 = q + seg_row0[s] * q_stride;
       hipError_t e = rr_launch_attention(q0, q_stride, 1, 0, k + seg_row0[s] * kv_stride, v + seg_row0[s] * kv_stride, kv_stride,
                                          key_bias ? key_bias + seg_row0[s] : nullptr, seg_n[s], heads, seg_len[s], seg_len[s],
-                                         out + seg_row0[s] * out_stride, out_stride, dt, st, nullptr, 0, schedule_blocks);
+                                         out + seg_row0[s] * out_stride, out_stride, dt, st, nullptr, 0, schedule_blocks, fixed_mode);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -2215,13 +2215,20 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
 }
 
 std::atomic<int> g_resid_split{1};       // rr_set_tuning("resid_split")
+// Smallest problem (in 256 x 256 tiles) that runs the persistent ring; below it the 128 x 128 two-stage kernel.  Measured per
+// shape at the strong-scaling shard sizes of one K = 100 query (profiles/r04_e_midsize_variants.log, M = 6 656 / 12 800 / 25 600):
+// the ring wins from ~150 tiles on (one tile per CU on 60 % of the chip beats three 128 x 128 tiles per CU: QKV 26 vs 37 us at
+// 234 tiles, attention-out 33 vs 43 us at 150) and loses at 78 (28 vs 24 us).  Rounds 1-3 used 512.
+std::atomic<int> g_ring_min_tiles{128};  // rr_set_tuning("gemm_ring_min_tiles")
+extern "C" int rr_set_gemm_ring_min_tiles(int n) { if (n < 1) return -1; g_ring_min_tiles.store(n); return 0; }
 extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return 0; }
+extern "C" int rr_get_resid_split(void) { return g_resid_split.load(); }
 // The shape heuristic of rr_launch_gemm_fold, for callers that must know beforehand whether the split residual stream
 // is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
 bool rr_gemm_split_ok(int M, int N) {
   static const bool env_variant = getenv("RR_GEMM_VARIANT") != nullptr;     // read once: an environment override pins a kernel
-  if (!g_resid_split.load() || (g_variant.load() >= 0 && g_variant.load() < 15) || !g_persistent || env_variant) return false;
-  return (long)((M + 255) / 256) * ((N + 255) / 256) >= 512 && !(N & 7);
+  if ((g_variant.load() >= 0 && g_variant.load() < 15) || !g_persistent || env_variant) return false;   // ("resid_split" on / off is the caller's: a handle option)
+  return (long)((M + 255) / 256) * ((N + 255) / 256) >= g_ring_min_tiles.load() && !(N & 7);
 }
 
 hipError_t rr_launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias,
@@ -2268,7 +2275,7 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     // big problems: 256x256 tiles, persistent half-tile LDS ring (variant HP) with the LDS-staged coalesced epilogue; small ones:
     // 128x128 so the grid still fills 256 CUs (measured with tools/bench_gemm.py --stamps, profiles/).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    v = tiles256 >= 512 ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
+    v = tiles256 >= g_ring_min_tiles.load() ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
   }
   // 16-bit output forms of the persistent ring: the direct epilogue (gemm_kernel_hq) unless switched off; 16 / 17 force it
   // (17: its diagnostic build) and fall back to the staged kernel for the forms it does not implement

@@ -146,6 +146,10 @@ struct ProfEvent {
 
 }  // namespace
 
+// Options of a handle that change which arithmetic a forward runs (include/rerank_mi355.h, rr_set_option)
+enum RrOption { RR_OPT_LN_LITE = 0, RR_OPT_LN_FOLD, RR_OPT_CE_CLS_ONLY, RR_OPT_FP8_FFN_DOWN, RR_OPT_RESID_SPLIT, RR_OPT_ATTN_FIXED_REF, RR_OPT_COUNT };
+static const char* const kOptionKeys[RR_OPT_COUNT] = {"ln_lite", "ln_fold", "ce_cls_only", "fp8_ffn_down", "resid_split", "attn_fixed_ref"};
+
 struct rr_model {
   rr_config cfg;
   int dt = 0;                       // 16-bit operand dtype: 0 bf16, 1 fp16 (cfg.compute_dtype)
@@ -181,6 +185,9 @@ struct rr_model {
   const float* cls_rows = nullptr;     // set by run_cross_encoder when its last layer ran on the CLS rows only: [n, Hc] fp32 (else null)
   int* range_flag = nullptr;           // device word raised by ln_finalize when a residual row nears the fp16 range (rr_activation_range_flag)
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
+  // Per-handle numerics options (rr_set_option): -1 = follow the process-wide diagnostic switch of the same name (rr_set_tuning),
+  // 0 / 1 / ... = pinned for this handle.  Two handles of one process may differ (no global state on the path).
+  int opt[RR_OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
   bool pinned_blocks = false;          // a stream capture was seen on this handle: outgrown blocks are retired, not freed
   std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
 
@@ -701,6 +708,7 @@ extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 extern "C" int rr_set_resid_fast(int on);
 extern "C" int rr_set_gemm_direct(int on);
+extern "C" int rr_set_gemm_ring_min_tiles(int n);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
@@ -733,9 +741,23 @@ struct ResidSrc {
          rr_launch_gemm_fold(A, lda, Wf, K, dvec, nullptr, 0, nullptr, nullptr, nullptr, fold, C, ldc, M, N, K, epi, m->dt, st))
 
 int g_ce_cls_only = 1;                   // tuning (rr_set_tuning "ce_cls_only"): 1 = the cross-encoder's last layer computes the CLS rows only
-int g_fp8_ffn_down = 1;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too
+int g_fp8_ffn_down = 0;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too (opt-in: ADVICE r3, DESIGN.md "fp8")
 constexpr float FP8_GELU_MUL = 8.0f;     // static scale of the e4m3 GELU output feeding it
 int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
+
+extern "C" int rr_get_resid_split(void);
+// effective value of a handle option: the handle's own setting, else the process-wide switch
+inline int opt_of(const rr_model* m, int which) {
+  if (m->opt[which] >= 0) return m->opt[which];
+  switch (which) {
+    case RR_OPT_LN_LITE: return g_ln_lite;
+    case RR_OPT_LN_FOLD: return g_ln_fold;
+    case RR_OPT_CE_CLS_ONLY: return g_ce_cls_only;
+    case RR_OPT_FP8_FFN_DOWN: return g_fp8_ffn_down;
+    case RR_OPT_RESID_SPLIT: return rr_get_resid_split();
+    default: return -1;      // RR_OPT_ATTN_FIXED_REF: -1 lets the attention launcher take its own process-wide mode
+  }
+}
 
 // One post-LN BertLayer over `rows` = batch*Tseq rows (self-attention only).
 // In: the previous LayerNorm's output as MFMA operand in w.h16 — either normalised (`folded_in` false: after an embedding
@@ -778,8 +800,10 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     rows = (int)r;
   }
   const int nparts = (Hd + 127) / 128;
-  const bool fp8 = m->cfg.fp8 && g_ln_lite && L.w1_8 && (Hd % 128 == 0);
-  const bool fold = !fp8 && g_ln_fold && g_ln_lite && L.w1_f && (Hd % 8 == 0);
+  const bool ln_lite = opt_of(m, RR_OPT_LN_LITE) != 0;
+  const int attn_mode = opt_of(m, RR_OPT_ATTN_FIXED_REF);
+  const bool fp8 = m->cfg.fp8 && ln_lite && L.w1_8 && (Hd % 128 == 0);
+  const bool fold = !fp8 && opt_of(m, RR_OPT_LN_FOLD) && ln_lite && L.w1_f && (Hd % 8 == 0);
   if (in_kind == OP_RAW_FOLDED) {
     if (!L.wqkv_f) return fail(m, RR_ERR_BAD_ARG, "internal: folded operand into a layer without folded QKV weights");
     GemmFold f;
@@ -805,13 +829,13 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     }
     RR_RUN(m, st, RR_K_ATTENTION, fl, 2.0 * 4.0 * rows * Hd,
            rr_launch_attention_segs(w.qkv, 3 * Hd, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, heads, (int)sn.size(), sn.data(),
-                                    sl.data(), sr.data(), w.ctx, Hd, m->dt, st, sched));
+                                    sl.data(), sr.data(), w.ctx, Hd, m->dt, st, sched, attn_mode));
   } else {
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * batch * (double)Tseq * Tseq * Hd, 2.0 * 4.0 * rows * Hd,
            rr_launch_attention(w.qkv, 3 * Hd, 1, 0, w.qkv + Hd, w.qkv + 2 * Hd, 3 * Hd, key_bias, batch, heads, Tseq,
-                               Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld));
+                               Tseq, w.ctx, Hd, m->dt, st, dense_bias, dense_ld, 0, attn_mode));
   }
-  if (!g_ln_lite) {   // reference dataflow for A/B runs: every LayerNorm writes the fp32 stream, residuals read it back
+  if (!ln_lite) {   // reference dataflow for A/B runs: every LayerNorm writes the fp32 stream, residuals read it back
     RR_GEMM_LN(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rows * Hd,
            rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, eps, rows, Hd, w.h32, w.h16, m->dt, st));
@@ -835,7 +859,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     // persistent kernel: the GELU epilogue of FFN-up emits e4m3 bytes under ONE static power-of-two scale (GELU's range is
     // [-0.17, max pre-activation]: x 8 keeps 3 mantissa bits down to 2e-3 and saturates at 56), FFN-down multiplies its
     // accumulators by 1/8 and its per-channel weight scales and adds the LayerNorm-recomputed residual row in its epilogue
-    const bool down8 = g_fp8_ffn_down && L.w2_8 && (I % 128 == 0) && rr_gemm_fp8_ring_ok(rows, I, Hd) && rr_gemm_fp8_ring_ok(rows, Hd, I);
+    const bool down8 = opt_of(m, RR_OPT_FP8_FFN_DOWN) && L.w2_8 && (I % 128 == 0) && rr_gemm_fp8_ring_ok(rows, I, Hd) && rr_gemm_fp8_ring_ok(rows, Hd, I);
     if (down8) {
       RR_RUN(m, st, RR_K_GEMM_FP8, gemm_flops(rows, I, Hd), 1.0 * rows * Hd + 1.0 * I * Hd + 1.0 * rows * I + 4.0 * rows,
              rr_launch_gemm_fp8((const uint8_t*)w.h16, Hd, L.w1_8, Hd, L.b1, 1.0f, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 3, m->dt, st,
@@ -866,7 +890,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     // residual epilogues (an element is read and written by the same thread), instead of a third, fp32 copy: 8 instead of
     // 10 bytes per element through the two HBM-bound epilogues of a layer.  The last layer of a stack writes fp32 rows
     // (w.pre2) for the LayerNorm kernel that materialises the stack's output.
-    const bool split = rr_gemm_split_ok(rows, Hd);
+    const bool split = opt_of(m, RR_OPT_RESID_SPLIT) && rr_gemm_split_ok(rows, Hd);
     bf16_t* const lo16 = (bf16_t*)w.pre;
     GemmFold fo;
     fo.x16 = w.h16;
@@ -975,7 +999,7 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
   for (const Seg& g : segs) n += g.n;
   RR_GEMM(m, st, w.li16, D, m->w_cemap, m->b_cemap, nullptr, 0, w.pre, Hc, RT, Hc, D, EPI_BIAS_F32, 4.0);
   std::vector<SegView> view;
-  const bool cls_only = g_ce_cls_only && !m->debug && !adj && c.ce_layers == 1;
+  const bool cls_only = opt_of(m, RR_OPT_CE_CLS_ONLY) && !m->debug && !adj && c.ce_layers == 1;
   for (const Seg& g : segs) {      // (cls_only: the fp32 copy of the embedding rows is the residual of the CLS rows only)
     RR_RUN(m, st, RR_K_EMBED, 0.0, (cls_only ? 10.0 : 14.0) * g.n * g.T * Hc,
            rr_launch_ce_embed_ln(w.pre + g.rt0 * Hc, m->ce_pos, m->ce_type, m->ce_emb_g, m->ce_emb_b, c.ln_eps, g.n * g.T, g.T, Hc,
@@ -1018,7 +1042,8 @@ int run_cross_encoder(rr_model* m, hipStream_t st, Work& w, const std::vector<Se
       const bf16_t* kv = w.qkv + g.rt0 * 3 * Hc;
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * g.n * (double)g.T * Hc, 2.0 * 2.0 * g.n * g.T * Hc,
              rr_launch_attention(q16 + g.p0 * Hc, Hc, 1, 0, kv + Hc, kv + 2 * Hc, 3 * Hc, w.ce_bias + g.rt0, g.n, heads, 1, g.T,
-                                 ctx16 + g.p0 * Hc, Hc, m->dt, st, nullptr, 0, (((long)n * heads + 7) / 8) * 8));   // (the one-segment call's schedule)
+                                 ctx16 + g.p0 * Hc, Hc, m->dt, st, nullptr, 0, (((long)n * heads + 7) / 8) * 8,   // (the one-segment call's schedule)
+                                 opt_of(m, RR_OPT_ATTN_FIXED_REF)));
     }
     RR_GEMM(m, st, ctx16, Hc, L.wo, L.bo, x32, Hc, pre_a, Hc, n, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * n * Hc, rr_launch_layernorm(pre_a, L.ln1g, L.ln1b, c.ln_eps, n, Hc, a32, a16, m->dt, st));
@@ -1359,7 +1384,7 @@ static int rr_encode_image_impl(rr_handle h, const float* pixel_values, int B, f
     RR_GEMM(m, st, w.n16, Vh, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Vh, R, 3 * Vh, Vh, EPI_BIAS_BF16, 2.0);
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * B * (double)T * T * Vh, 2.0 * 4.0 * R * Vh,
            rr_launch_attention(w.qkv, 3 * Vh, 1, 0, w.qkv + Vh, w.qkv + 2 * Vh, 3 * Vh, nullptr, B, c.vit_heads, T, T,
-                               w.ctx, Vh, m->dt, st));
+                               w.ctx, Vh, m->dt, st, nullptr, 0, 0, opt_of(m, RR_OPT_ATTN_FIXED_REF)));
     RR_GEMM(m, st, w.ctx, Vh, L.wo, L.bo, x, Vh, y, Vh, R, Vh, Vh, EPI_BIAS_RESID_F32, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 6.0 * R * Vh, rr_launch_layernorm(y, L.ln2g, L.ln2b, eps, R, Vh, nullptr, w.n16, m->dt, st));
     RR_GEMM(m, st, w.n16, Vh, L.w1, L.b1, nullptr, 0, w.mid, Iv, R, Iv, Vh, EPI_BIAS_QGELU_BF16, 2.0);
@@ -1560,7 +1585,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
       RR_GEMM(m, st, tin16, Hd, L.wqkv, L.bqkv, nullptr, 0, w.vqkv, 3 * Hd, bt * np, 3 * Hd, Hd, EPI_BIAS_BF16, 2.0);
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * bt * (double)np * np * Hd, 8.0 * bt * np * Hd,
              rr_launch_attention(w.vqkv, 3 * Hd, 1, 0, w.vqkv + Hd, w.vqkv + 2 * Hd, 3 * Hd, nullptr, bt, c.heads, np, np,
-                                 w.vctx, Hd, m->dt, st));
+                                 w.vctx, Hd, m->dt, st, nullptr, 0, 0, opt_of(m, RR_OPT_ATTN_FIXED_REF)));
       RR_GEMM(m, st, w.vctx, Hd, L.wo, L.bo, tin32, Hd, w.vpre, Hd, bt * np, Hd, Hd, EPI_BIAS_RESID_F32, 4.0);
       RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * bt * np * Hd,
              rr_launch_layernorm(w.vpre, L.ln1g, L.ln1b, c.ln_eps, bt * np, Hd, w.a32, w.a16, m->dt, st));
@@ -1569,7 +1594,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
       RR_GEMM(m, st, w.enc16, Hd, L.wkv_c, L.bkv_c, nullptr, 0, w.kv_c, 2 * Hd, n * ca, 2 * Hd, Hd, EPI_BIAS_BF16, 2.0);
       RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)np * ca * Hd, 2.0 * n * (2.0 * np + 2.0 * ca) * Hd,
              rr_launch_attention(w.q_c, Hd, per_query ? K : 1, per_query ? pair_begin - q_lo * K : 0, w.kv_c,
-                                 w.kv_c + Hd, 2 * Hd, nullptr, n, c.heads, np, ca, w.cctx, Hd, m->dt, st));
+                                 w.kv_c + Hd, 2 * Hd, nullptr, n, c.heads, np, ca, w.cctx, Hd, m->dt, st, nullptr, 0, 0, opt_of(m, RR_OPT_ATTN_FIXED_REF)));
       const float* resid = w.a32;
       if (per_query) {   // broadcast the per-query residual to the pairs
         RR_RUN(m, st, RR_K_TAIL, 0.0, 8.0 * n * np * Hd,
@@ -1757,7 +1782,7 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
     RR_GEMM(m, st, w.enc16, Hc, L.wkv_c, L.bkv_c, nullptr, 0, w.kv_c, 2 * Hc, n * Lc, 2 * Hc, Hc, EPI_BIAS_BF16, 2.0);
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)Lq * Lc * Hc, 2.0 * n * (2.0 * Lq + 2.0 * Lc) * Hc,
            rr_launch_attention(w.q_c, Hc, 1, 0, w.kv_c, w.kv_c + Hc, 2 * Hc, w.li32, n, c.ce_heads, Lq, Lc, w.ctx, Hc,
-                               m->dt, st));
+                               m->dt, st, nullptr, 0, 0, opt_of(m, RR_OPT_ATTN_FIXED_REF)));
     RR_GEMM(m, st, w.ctx, Hc, L.wo_c, L.bo_c, w.h32, Hc, w.pre, Hc, rq, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rq * Hc,
            rr_launch_layernorm(w.pre, L.lncg, L.lncb, c.ln_eps, rq, Hc, w.a32, w.a16, m->dt, st));
@@ -1765,7 +1790,7 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
     RR_GEMM(m, st, w.a16, Hc, L.wqkv, L.bqkv, nullptr, 0, w.qkv, 3 * Hc, rq, 3 * Hc, Hc, EPI_BIAS_BF16, 2.0);
     RR_RUN(m, st, RR_K_ATTENTION, 4.0 * n * (double)Lq * Lq * Hc, 8.0 * rq * Hc,
            rr_launch_attention(w.qkv, 3 * Hc, 1, 0, w.qkv + Hc, w.qkv + 2 * Hc, 3 * Hc, w.text_bias, n, c.ce_heads, Lq, Lq,
-                               w.ctx, Hc, m->dt, st));
+                               w.ctx, Hc, m->dt, st, nullptr, 0, 0, opt_of(m, RR_OPT_ATTN_FIXED_REF)));
     RR_GEMM(m, st, w.ctx, Hc, L.wo, L.bo, w.a32, Hc, w.pre, Hc, rq, Hc, Hc, EPI_BIAS_RESID_F32, 4.0);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 10.0 * rq * Hc,
            rr_launch_layernorm(w.pre, L.ln1g, L.ln1b, c.ln_eps, rq, Hc, w.a32, w.a16, m->dt, st));
@@ -1855,6 +1880,30 @@ static int rr_get_profile_impl(rr_handle h, rr_profile* out, int reset) {
   return RR_OK;
 }
 
+// ---- per-handle numerics options ---------------------------------------------------------------
+static int option_index(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < RR_OPT_COUNT; ++i)
+    if (!strcmp(key, kOptionKeys[i])) return i;
+  return -1;
+}
+int rr_set_option(rr_handle h, const char* key, int value) {
+  if (!h) return RR_ERR_BAD_ARG;
+  const int i = option_index(key);
+  if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_set_option: unknown key '%s'", key ? key : "(null)");
+  if (value < -1 || (i != RR_OPT_ATTN_FIXED_REF && value > 1) || value > 3)
+    return fail(h, RR_ERR_BAD_ARG, "rr_set_option: %s = %d out of range", key, value);
+  h->opt[i] = value;
+  return RR_OK;
+}
+int rr_get_option(rr_handle h, const char* key, int* value_out) {
+  if (!h || !value_out) return RR_ERR_BAD_ARG;
+  const int i = option_index(key);
+  if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_get_option: unknown key '%s'", key ? key : "(null)");
+  *value_out = opt_of(h, i);
+  return RR_OK;
+}
+
 // ---- stand-alone operators ---------------------------------------------------------------------
 int rr_set_tuning(const char* key, int value) {
   if (!key) return RR_ERR_BAD_ARG;
@@ -1867,6 +1916,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "resid_fast")) return rr_set_resid_fast(value);
   if (!strcmp(key, "gemm_direct")) return rr_set_gemm_direct(value);
+  if (!strcmp(key, "gemm_ring_min_tiles")) return rr_set_gemm_ring_min_tiles(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);

@@ -312,11 +312,12 @@ hipError_t rr_launch_layernorm_q8(const float* x, const float* gamma, const floa
 hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, int q_batch_off, const bf16_t* k,
                                const bf16_t* v, int kv_stride, const float* key_bias, int B,
                                int heads, int Tq, int Tk, bf16_t* out, int out_stride, int dt,
-                               hipStream_t st, const float* dense_bias = nullptr, int dense_ld = 0, long schedule_blocks = 0);
+                               hipStream_t st, const float* dense_bias = nullptr, int dense_ld = 0, long schedule_blocks = 0,
+                               int fixed_mode = -1);
 hipError_t rr_launch_attention_segs(const bf16_t* q, int q_stride, const bf16_t* k, const bf16_t* v, int kv_stride,
                                     const float* key_bias, int heads, int nseg, const int* seg_n, const int* seg_len,
                                     const long long* seg_row0, bf16_t* out, int out_stride, int dt, hipStream_t st,
-                                    long schedule_blocks);
+                                    long schedule_blocks, int fixed_mode = -1);
 // dense_bias: optional additive bias [B][Tq][dense_ld] (dense_ld a multiple of 64 >= Tk, zero padded), PreFLMR fusion
 hipError_t rr_launch_fusion_adj(const float* scores, int S, int Tq, int Tc, float mult, int pair0, int n, float* adj, int ld,
                                 hipStream_t st, int row0 = 2);

@@ -561,6 +561,17 @@ class RerankEngine:
     def workspace_bytes(self, n_pairs: int, S: int) -> int:
         return int(self.lib.rr_workspace_bytes(self.h, n_pairs, S))
 
+    def set_option(self, key: str, value: int):
+        """Pin a numerics option of THIS engine (rr_set_option: "ln_lite", "ln_fold", "resid_split", "ce_cls_only",
+        "fp8_ffn_down", "attn_fixed_ref"); -1 = follow the process-wide diagnostic switch again."""
+        L.check(self.lib.rr_set_option(self.h, key.encode(), int(value)), self.h, "rr_set_option")
+
+    def get_option(self, key: str) -> int:
+        import ctypes
+        v = ctypes.c_int(0)
+        L.check(self.lib.rr_get_option(self.h, key.encode(), ctypes.byref(v)), self.h, "rr_get_option")
+        return int(v.value)
+
     def reserve(self, n_pairs: int, n_queries: int, len_a: int, len_b: int = 0, with_fusion: bool = False,
                 packed: bool = False):
         """Allocate everything a forward of at most this shape needs (rr_reserve) on the current stream: afterwards the

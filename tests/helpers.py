@@ -97,10 +97,19 @@ def margin_stats(got, ref):
                 n=int(got.numel()), ref_std=float(ref.std()) if got.numel() > 1 else 0.0)
 
 
+_RUN_TAG = None
+
+
 def record_margin(key, **metrics):
-    """Append measured parity margins to a JSON the builder commits as profiles/rNN_parity_margins.json (`pytest -q` prints
-    nothing): $RR_MARGINS_JSON or gpurun_out/parity_margins.json under the repo root.  Never fails a test."""
+    """Append measured parity margins to a JSON (`pytest -q` prints nothing): $RR_MARGINS_JSON or gpurun_out/parity_margins.json
+    under the repo root.  The builder folds it into the committed profiles/rNN_parity_margins.json with tools/merge_margins.py,
+    which never drops a key.  Every entry carries `run` = start time + pid of the pytest process that wrote it.
+    Never fails a test."""
     import json
+    import time
+    global _RUN_TAG
+    if _RUN_TAG is None:
+        _RUN_TAG = time.strftime("%Y%m%dT%H%M%S") + f"-{os.getpid()}"
     path = os.environ.get("RR_MARGINS_JSON", os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -108,6 +117,7 @@ def record_margin(key, **metrics):
         if os.path.exists(path):
             with open(path) as f:
                 data = json.load(f)
+        metrics = dict(metrics, run=_RUN_TAG)
         data[key] = metrics
         with open(path, "w") as f:
             json.dump(data, f, indent=1, sort_keys=True)

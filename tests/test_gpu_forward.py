@@ -560,6 +560,51 @@ def test_cls_only_cross_encoder_layer_equals_the_all_rows_layer(name):
         assert (cls_only["logits2"] - all_rows["logits2"]).abs().max().item() <= 5e-4
 
 
+def test_two_handles_in_one_process_may_differ_in_their_numerics_options():
+    """SURVEY 8(b) "no global state => several handles per process" (VERDICT r3 item 7): what changes the arithmetic of a forward
+    is a handle option (rr_set_option).  Two engines on the same weights, one with the all-rows cross-encoder layer, fp32
+    residual rows and LayerNorm kernels, the other with the defaults, run INTERLEAVED: each reproduces exactly what a lone engine
+    gives under the process-wide diagnostic switch of the same name, neither leaks into the other, and the effective values
+    read back."""
+    from rmr_amd import _lib
+    lib = _lib.load()
+    g = load_golden("c2")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=False)
+    ids, am, tt, _ = golden_inputs(g)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], None, None, None)
+    pinned = {"ce_cls_only": 0, "resid_split": 0, "ln_fold": 0}
+    a, b = _engine(cfg, False, w, "fp16"), _engine(cfg, False, w, "fp16")
+    for k, v in pinned.items():
+        a.set_option(k, v)
+    assert all(a.get_option(k) == v for k, v in pinned.items()) and all(b.get_option(k) == 1 for k in pinned)
+    with pytest.raises(ValueError):
+        a.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        a.set_option("ln_fold", 2)
+    ra1, rb1, ra2, rb2 = a.forward_ids(*args), b.forward_ids(*args), a.forward_ids(*args), b.forward_ids(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(ra1["logits"], ra2["logits"]) and torch.equal(rb1["logits"], rb2["logits"])
+    assert not torch.equal(ra1["logits"], rb1["logits"])             # different arithmetic (re-decided roundings) ...
+    assert (ra1["logits"] - rb1["logits"]).abs().max().item() < 1e-3  # ... of the same function
+    lone = _engine(cfg, False, w, "fp16")
+    try:
+        for k, v in pinned.items():
+            assert lib.rr_set_tuning(k.encode(), v) == 0
+        assert b.get_option("ln_fold") == 0                            # an unpinned handle follows the process-wide switch
+        rl = lone.forward_ids(*args)
+        b.set_option("ln_fold", 1); b.set_option("ce_cls_only", 1); b.set_option("resid_split", 1)   # pinned: immune to it
+        rb3 = b.forward_ids(*args)
+    finally:
+        for k in pinned:
+            lib.rr_set_tuning(k.encode(), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(rl["logits"], ra1["logits"])
+    assert torch.equal(rb3["logits"], rb1["logits"])
+    a.set_option("ce_cls_only", -1); a.set_option("resid_split", -1); a.set_option("ln_fold", -1)
+    assert torch.equal(a.forward_ids(*args)["logits"], rb1["logits"])
+
+
 @pytest.mark.parametrize("S,n", [(4, 1), (3, 1), (2, 3), (6, 2)])
 def test_cls_only_layer_on_very_short_rows(S, n):
     """the CLS-only layer's eleven n-row buffers were carved out of the FFN intermediate (n * T * I * 2 bytes) with no
@@ -573,7 +618,10 @@ def test_cls_only_layer_on_very_short_rows(S, n):
     cfg = g["cfg"]
     w = O.make_weights(cfg, seed=0, vision=False)
     eng = _engine(cfg, False, w, "fp16")
-    ids, am, tt = O.make_pair_batch(cfg, n, 1, S, seed=3)
+    gen = torch.Generator().manual_seed(3 + S)                # (make_pair_batch needs S >= 5: [CLS] q [SEP] ctx [SEP])
+    ids = torch.randint(1000, cfg.vocab_size, (n, S), generator=gen)
+    ids[:, 0], ids[:, -1] = 101, 102
+    am, tt = torch.ones_like(ids), torch.zeros_like(ids)
     args = (ids.cuda(), am.cuda(), tt.cuda(), n, 1, None, None, None)
     a = eng.forward_ids(*args)
     try:

@@ -1,13 +1,14 @@
 """CPU: the oracle against the committed golden vectors (generated from the stock-HF assembly by
 tests/golden/make_golden.py), plus the head/rank/metric restatements against hand-computed cases."""
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import O, golden_inputs, load_golden
+from helpers import GOLDEN, O, golden_inputs, load_golden
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_mm", "tiny_2h", "c1"])
@@ -160,3 +161,27 @@ def test_attention_fusion_oracle_matches_golden():
     assert adj[:, :Tq, :Tq].abs().max() == 0 and adj[:, Tq:, Tq:].abs().max() == 0
     assert torch.allclose(adj[:, :Tq, Tq:].sum(-1), torch.ones(adj.shape[0], Tq), atol=1e-5)
     assert torch.allclose(adj[:, Tq:, :Tq].sum(-1), torch.ones(adj.shape[0], adj.shape[1] - Tq), atol=1e-5)
+
+
+@pytest.mark.parametrize("name,K,gap", [("c3_sep", 100, 0.08), ("c5_sep", 200, 0.12)])
+def test_ranking_fixtures_are_what_they_claim(name, K, gap):
+    """The Recall@5 fixtures (tests/golden/make_golden.py run_fullsize_case) without a GPU: per query a list of K distinct pool
+    candidates whose fp32 stock-HF logits leave the designed gap between rank 5 and rank 6, the single positive at fp32 rank 5
+    (query 0) / rank 6 (query 1), so that the reference ranking gives Recall@5 = (1, 0) and Recall@10 = (1, 1)."""
+    import numpy as np
+    from oracle import rerank_oracle as O
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    assert int(z["nq"]) == 2
+    ranked, pos = [], []
+    for qi in range(2):
+        sel = z[f"q{qi}.selected"]
+        assert len(sel) == K and len(set(sel.tolist())) == K and sel.max() < int(z["pool"])
+        ref = z[f"q{qi}.pool_logits"][sel]
+        order = O.rank_descending_stable(ref.tolist())
+        s = np.sort(ref)[::-1]
+        assert s[4] - s[5] >= gap and abs((s[4] - s[5]) - float(z[f"q{qi}.gap_5_6"])) < 1e-6
+        p = int(z[f"q{qi}.positive_list_index"])
+        assert order.index(p) == (4 if qi == 0 else 5)
+        ranked.append(order)
+        pos.append([p])
+    assert O.recall_precision_at_k(ranked, pos, [5, 10])["recall"] == [0.5, 1.0]
