@@ -432,6 +432,13 @@ def main():
             res["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in prof.items()}
             a = prof["attention"]
             res["attention_tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+            # FLOPs of the launches that RAN (GEMMs + attention of this rank), over the wall time of the timed steps: the
+            # executed rate beside the reference-equivalent whole_path_* (which counts the rows of the cross-encoder layer
+            # the library does not compute)
+            exe = sum(v["flops"] for v in prof.values())
+            res["executed_tflops_per_gpu"] = exe / dt / 1e12
+            res["executed_frac_of_bf16_peak"] = exe / dt / 1e12 / PEAK_BF16_TFLOPS
+            res["executed_gflop_per_pair"] = exe / max(1, (N // world) * args.steps) / 1e9
         if world == 1 and not args.no_e2e:
             # the window the reference prints as "Rerank time" (Reranker_base_executor.py:898-939), for ONE query of K
             # candidates: host ids -> device, forward, logits/order back to the host (the sort runs on the device)
@@ -456,8 +463,8 @@ def main():
         if world == 1 and not args.no_alt_dtype and not args.bucketed and not args.packed:
             # The library computes the cross-encoder's last layer behind its K / V projection for the CLS rows only (the classifiers
             # read hidden state [:, 0]; same logits up to rounding).  The same step with every row of that layer computed, as the
-            # reference does, is reported beside the headline (rr_set_tuning "ce_cls_only" 0).
-            assert eng.lib.rr_set_tuning(b"ce_cls_only", 0) == 0
+            # reference does, is reported beside the headline (rr_set_option "ce_cls_only" 0).
+            eng.set_option("ce_cls_only", 0)                       # a handle option: nothing process-wide changes
             try:
                 for _ in range(max(1, args.warmup)):
                     eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
@@ -467,9 +474,9 @@ def main():
                     eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
                 torch.cuda.synchronize(dev)
                 res["all_cross_encoder_rows_mode"] = {"value": N * args.steps / (time.perf_counter() - t1), "unit": "pairs/s",
-                                                      "note": "the last cross-encoder layer computed for all rows (rr_set_tuning ce_cls_only 0)"}
+                                                      "note": "the last cross-encoder layer computed for all rows (handle option ce_cls_only = 0)"}
             finally:
-                eng.lib.rr_set_tuning(b"ce_cls_only", 1)
+                eng.set_option("ce_cls_only", -1)
         if world == 1 and not args.no_alt_dtype and not args.fp8:
             # the same kernels with the other 16-bit operand type
             alt = "bf16" if args.compute_dtype == "fp16" else "fp16"

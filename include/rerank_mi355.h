@@ -53,7 +53,9 @@ typedef enum rr_status {
   RR_ERR_HIP = -5,          /* a HIP runtime call failed                           (Python: RuntimeError)        */
   RR_ERR_OOM = -6,          /* device allocation failed                            (Python: MemoryError)         */
   RR_ERR_MISSING_WEIGHT = -7, /* rr_finalize_weights: a required tensor was never loaded (Python: KeyError)      */
-  RR_ERR_NO_DEVICE = -8     /* no gfx950 device visible                            (Python: RuntimeError)        */
+  RR_ERR_NO_DEVICE = -8,    /* no gfx950 device visible                            (Python: RuntimeError)        */
+  RR_ERR_RANGE = -9         /* an EARLIER forward of this handle raised the fp16 activation range flag: its logits are
+                               unreliable (rr_activation_range_flag below; no reference counterpart) (Python: OverflowError) */
 } rr_status;
 
 typedef enum rr_dtype { RR_F32 = 0, RR_BF16 = 1, RR_F16 = 2 } rr_dtype;
@@ -202,7 +204,12 @@ int rr_get_option(rr_handle h, const char* key, int* value_out);
  * exceed 3e4) or is not finite; BERT-family activations stay four orders of magnitude below.  rr_activation_range_flag
  * copies the flag to *flag_out (synchronises `hip_stream`; call it outside the hot loop, e.g. once per evaluation batch
  * group) and clears it when reset != 0.  A raised flag means: rebuild the handle with compute_dtype = 0 (bf16, the
- * reference's autocast type, same exponent range as fp32).  Python: RerankEngine.activation_range_exceeded(). */
+ * reference's autocast type, same exponent range as fp32).  Python: RerankEngine.activation_range_exceeded().  * STICKY ERROR: every forward ends with an asynchronous copy of the flag word into pinned host memory (no synchronisation), and
+ * every forward BEGINS by looking at that word: once a forward has raised the flag, the next rr_forward* call on the handle
+ * returns RR_ERR_RANGE instead of computing — a caller that never polls cannot keep ranking with out-of-range activations for
+ * more than the one batch whose logits it was about to read anyway.  rr_activation_range_flag(reset = 1) clears it (then build
+ * the handle with compute_dtype = bf16 for this checkpoint).
+ */
 int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_stream);
 
 /* rr_forward_packed: the same computation over PACKED rows (SURVEY.md "Variable length"): the caller

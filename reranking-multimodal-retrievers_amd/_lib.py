@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "librerank_mi355.so")
 
 RR_ABI_VERSION = 2
 RR_OK, RR_ERR_BAD_ARG, RR_ERR_BAD_SHAPE, RR_ERR_BAD_DTYPE, RR_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-RR_ERR_HIP, RR_ERR_OOM, RR_ERR_MISSING_WEIGHT, RR_ERR_NO_DEVICE = -5, -6, -7, -8
+RR_ERR_HIP, RR_ERR_OOM, RR_ERR_MISSING_WEIGHT, RR_ERR_NO_DEVICE, RR_ERR_RANGE = -5, -6, -7, -8, -9
 RR_F32, RR_BF16, RR_F16 = 0, 1, 2
 LOSS_KINDS = {"BCE": 0, "2H_BCE": 1, "negative_sampling": 2}
 COMPUTE_DTYPES = {"bf16": 0, "fp16": 1}
@@ -44,7 +44,7 @@ class RRProfile(C.Structure):
 # exceptions mirror the reference's Python error behaviour (include/rerank_mi355.h rr_status comments)
 _EXC = {RR_ERR_BAD_ARG: ValueError, RR_ERR_BAD_SHAPE: AssertionError, RR_ERR_BAD_DTYPE: ValueError,
         RR_ERR_UNSUPPORTED: NotImplementedError, RR_ERR_HIP: RuntimeError, RR_ERR_OOM: MemoryError,
-        RR_ERR_MISSING_WEIGHT: KeyError, RR_ERR_NO_DEVICE: RuntimeError}
+        RR_ERR_MISSING_WEIGHT: KeyError, RR_ERR_NO_DEVICE: RuntimeError, RR_ERR_RANGE: OverflowError}
 
 _P = C.c_void_p
 _SIGS = {

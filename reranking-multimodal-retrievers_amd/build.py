@@ -84,7 +84,13 @@ def check_no_packed_f32(obj: str) -> None:
         shutil.rmtree(d, ignore_errors=True)
 
 
+LAST_BUILD: dict = {}      # what the last build_library call did (also written to build/build_record.json)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    import json
+    import time
+    lib_existed = os.path.exists(LIB)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -119,6 +125,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 os.remove(obj)
                 raise
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs])
+        linked = True
+    else:
+        linked = False
+    LAST_BUILD.clear()
+    LAST_BUILD.update(compiled=[os.path.basename(j[-3]) for j in jobs], linked=linked, reused_prebuilt_library=lib_existed and not linked,
+                      forced=bool(force), when=time.strftime("%Y-%m-%dT%H:%M:%S"))
+    try:
+        with open(os.path.join(objdir, "build_record.json"), "w") as f:
+            json.dump(LAST_BUILD, f, indent=1)
+    except OSError:
+        pass
     return LIB
 
 

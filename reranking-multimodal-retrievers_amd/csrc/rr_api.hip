@@ -183,6 +183,7 @@ struct rr_model {
   char* ws = nullptr;
   size_t ws_cap = 0;
   const float* cls_rows = nullptr;     // set by run_cross_encoder when its last layer ran on the CLS rows only: [n, Hc] fp32 (else null)
+  int* range_flag_host = nullptr;      // pinned copy of range_flag, refreshed asynchronously at the end of every forward (sticky RR_ERR_RANGE)
   int* range_flag = nullptr;           // device word raised by ln_finalize when a residual row nears the fp16 range (rr_activation_range_flag)
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
   // Per-handle numerics options (rr_set_option): -1 = follow the process-wide diagnostic switch of the same name (rr_set_tuning),
@@ -1122,6 +1123,7 @@ const char* rr_status_string(int s) {
     case RR_ERR_OOM: return "out of device memory";
     case RR_ERR_MISSING_WEIGHT: return "missing weight";
     case RR_ERR_NO_DEVICE: return "no gfx950 device";
+    case RR_ERR_RANGE: return "fp16 activation range exceeded in an earlier forward";
     default: return "unknown status";
   }
 }
@@ -1189,6 +1191,7 @@ static int rr_destroy_impl(rr_handle h) {
   (void)hipDeviceSynchronize();
   for (void* p : h->dev_allocs) (void)hipFree(p);
   for (void* p : h->retired) (void)hipFree(p);
+  if (h->range_flag_host) (void)hipHostFree(h->range_flag_host);
   if (h->ws) (void)hipFree(h->ws);
   if (h->tap_text) (void)hipFree(h->tap_text);
   if (h->adj) (void)hipFree(h->adj);
@@ -1242,6 +1245,8 @@ static int rr_finalize_weights_impl(rr_handle h) {
   if (!m->range_flag) {
     RR_TRY(dev_alloc(m, (void**)&m->range_flag, sizeof(int)));
     RR_HIP(m, hipMemset(m->range_flag, 0, sizeof(int)));
+    RR_HIP(m, hipHostMalloc((void**)&m->range_flag_host, sizeof(int), hipHostMallocDefault));
+    *m->range_flag_host = 0;
   }
   if (c.model_kind != RR_MODEL_FULL_CONTEXT) {
     RR_TRY(up_bf16(m, HT(m, "cross_encoder_input_mapping.weight"), &m->w_cemap));
@@ -1420,6 +1425,21 @@ static int rr_head_impl(rr_handle h, const float* logits, const float* logits2, 
 // joint != 0: RerankModel.forward semantics (rerank_model.py:171-331) on the pre-assembled joint sequence:
 // token types all 0, query_mask with instruction masking, cross-encoder order [query | image | context], and the
 // reference's `loss_fn(logits, logits)` quirk (:328).
+// Sticky range error (include/rerank_mi355.h, rr_activation_range_flag): look at what the PREVIOUS forwards left in the pinned
+// word (no synchronisation: a copy still in flight simply reports one call later), refuse to go on once it is raised.
+static int range_guard_enter(rr_model* m) {
+  if (m->range_flag_host && *(volatile int*)m->range_flag_host)
+    return fail(m, RR_ERR_RANGE, "an earlier forward's pre-LayerNorm rows left the fp16 range (flag %d): its logits are unreliable; "
+                                 "clear with rr_activation_range_flag(reset = 1) and use compute_dtype = bf16 for this checkpoint",
+                *(volatile int*)m->range_flag_host);
+  return RR_OK;
+}
+static int range_guard_exit(rr_model* m, hipStream_t st) {
+  if (m->range_flag && m->range_flag_host)
+    RR_HIP(m, hipMemcpyAsync(m->range_flag_host, m->range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  return RR_OK;
+}
+
 static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask,
                         const int64_t* token_type_ids, const float* image_cls, const float* image_patches, int Bq, int K,
                         int S, const float* labels, int pair_begin, int pair_end, float* logits_out,
@@ -1433,6 +1453,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   const rr_config& c = m->cfg;
   if (c.model_kind != RR_MODEL_FULL_CONTEXT) return fail(m, RR_ERR_BAD_ARG, "rr_forward on an interaction model; use rr_forward_interaction");
   if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_forward before rr_finalize_weights");
+  RR_TRY(range_guard_enter(m));
   if (!input_ids || !attention_mask || !logits_out) return fail(m, RR_ERR_BAD_ARG, "rr_forward: null input_ids/attention_mask/logits_out");
   if (Bq <= 0 || K <= 0 || S <= 0) return fail(m, RR_ERR_BAD_SHAPE, "rr_forward: Bq=%d K=%d S=%d", Bq, K, S);
   const int N = Bq * K;
@@ -1636,8 +1657,9 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
     adj = m->adj;
   }
   RR_TRY(run_cross_encoder(m, st, w, segs, adj, adj_ld, vis_pos0));
-  return run_heads(m, st, w, segs, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
-                   loss_out, scores_out, order_out, joint != 0);
+  RR_TRY(run_heads(m, st, w, segs, Bq, K, pair_begin, full, joint ? logits_out : labels, logits_out, logits2_out,
+                   loss_out, scores_out, order_out, joint != 0));
+  return range_guard_exit(m, st);
 }
 
 static int rr_forward_impl(rr_handle h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* token_type_ids,
@@ -1708,6 +1730,7 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
   const rr_config& c = m->cfg;
   if (c.model_kind == RR_MODEL_FULL_CONTEXT) return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction on a full-context model");
   if (!m->finalized) return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction before rr_finalize_weights");
+  RR_TRY(range_guard_enter(m));
   if (!query_li || !context_li || !query_mask || !context_mask || !logits_out)
     return fail(m, RR_ERR_BAD_ARG, "rr_forward_interaction: null tensor");
   if (Bq <= 0 || K <= 0 || Lq <= 0 || Lc <= 0) return fail(m, RR_ERR_BAD_SHAPE, "Bq=%d K=%d Lq=%d Lc=%d", Bq, K, Lq, Lc);
@@ -1760,8 +1783,9 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
     }
     const std::vector<Seg> one{Seg{n, T, T, 0, 0, 0}};
     RR_TRY(run_cross_encoder(m, st, w, one, adj, adj_ld));
-    return run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
-                     order_out);
+    RR_TRY(run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+                     order_out));
+    return range_guard_exit(m, st);
   }
   if (preflmr_scores) return fail(m, RR_ERR_UNSUPPORTED, "Attention adj is not implemented for MORES");   // mores_model.py:72-73
 
@@ -1803,8 +1827,9 @@ static int forward_interaction(rr_handle h, const float* query_li, const float* 
   m->tap_ce = w.h32;
   m->tap_ce_elems = (size_t)n * Lq * Hc;
   const std::vector<Seg> one{Seg{n, Lq, Lq, 0, 0, 0}};
-  return run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
-                   order_out);
+  RR_TRY(run_heads(m, st, w, one, Bq, K, pair_begin, full, labels, logits_out, logits2_out, loss_out, scores_out,
+                   order_out));
+  return range_guard_exit(m, st);
 }
 
 static int rr_forward_interaction_impl(rr_handle h, const float* query_li, const float* context_li, const float* query_mask,
@@ -2196,6 +2221,7 @@ int rr_activation_range_flag(rr_handle h, int reset, int* flag_out, void* hip_st
     RR_HIP(m, hipMemcpyAsync(flag_out, m->range_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     if (reset) RR_HIP(m, hipMemsetAsync(m->range_flag, 0, sizeof(int), st));
     RR_HIP(m, hipStreamSynchronize(st));
+    if (m->range_flag_host) *m->range_flag_host = reset ? 0 : *flag_out;
     return RR_OK;
   });
 }

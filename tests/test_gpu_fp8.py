@@ -358,48 +358,62 @@ def test_fp8_forward_bert_large_against_the_c5_golden():
         assert st["max_abs"] <= gate["abs"] and st["centred"] <= gate["centred"] and st["rho"] >= gate["rho"]
 
 
+def _rank_c5_sep(eng, qs, tag):
+    """(top-5 sets kept per query, Recall@5/10 of the engine, of the fp32 reference) on the c5_sep lists; margins recorded."""
+    import rmr_amd
+    from helpers import O, margin_stats, record_margin
+    ranked, ranked_ref, pos, kept = [], [], [], []
+    for qi, q in enumerate(qs):
+        sel = torch.from_numpy(q["selected"].astype(np.int64))
+        ids, am, tt = q["ids"][sel], q["am"][sel], q["tt"][sel]
+        r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), 1, len(sel), want_order=True)
+        torch.cuda.synchronize()
+        lg, ref = r["logits"].cpu(), q["fp32"][sel]
+        order, ref_order = r["order"][0].cpu().tolist(), O.rank_descending_stable(ref.tolist())
+        st = margin_stats(lg, ref)
+        gap = float(q["gap_5_6"])
+        ok = set(order[:5]) == set(ref_order[:5])
+        print(f"[c5_sep/{tag} q{qi}] |dlogit| {st['max_abs']:.3e} centred {st['centred']:.3e} rho {st['rho']:.4f} top-5 {st['top5']}; "
+              f"logit std {ref.std():.3f}, rank-5/6 gap {gap:.3f}; top-5 set {'kept' if ok else 'LOST'}")
+        record_margin(f"c5_sep/q{qi}/{tag}", gap_5_6=gap, top5_set_kept=bool(ok), **st)
+        assert torch.isfinite(lg).all() and order == O.rank_descending_stable(lg.tolist())
+        ranked.append(order); ranked_ref.append(ref_order); pos.append([int(q["positive_list_index"])]); kept.append(ok)
+    return kept, rmr_amd.recall_precision_at_k(ranked, pos, [5, 10]), O.recall_precision_at_k(ranked_ref, pos, [5, 10])
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_16_bit_ranking_on_c5_sep(dt):
+    """c5_sep = bert-large, widened weights (gain 2.5, as c3_sep), two queries x 200 candidates chosen from a
+    pool of 300 so that the fp32 stock-HF logits leave >= 0.12 between rank 5 and rank 6; query 0's only positive is the fp32
+    rank-5 candidate, query 1's the rank-6 one.  The 16-bit modes must deliver the fp32 reference's top-5 id SETS and
+    Recall@5 = (1, 0), Recall@10 = (1, 1) — fp16 with the drift well inside half the gap (measured 8.5e-3)."""
+    import rmr_amd
+    from helpers import arch_from_cfg, load_fullsize
+    cfg, w, vision, qs = load_fullsize("c5_sep")
+    eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, vision, dt))
+    eng.load_state_dict(w)
+    kept, got, want = _rank_c5_sep(eng, qs, dt)
+    assert want["recall"] == [0.5, 1.0]
+    assert all(kept) and got == want
+
+
 @pytest.mark.parametrize("down", [0, 1])
 def test_fp8_ranking_on_c5_sep(down):
-    """the ranking verdict of configs[4] in fp8.  c5_sep = bert-large, widened weights (gain 2.5, as c3_sep),
-    two queries x 200 candidates chosen from a pool of 300 so that the fp32 stock-HF logits leave a designed gap between rank 5
-    and rank 6; query 0's only positive is the fp32 rank-5 candidate, query 1's the rank-6 one.  What a configuration must
-    deliver to be a usable reranker: the fp32 reference's top-5 id SETS and Recall@5 = (1, 0).  The 16-bit mode is the control."""
+    """The ranking verdict of configs[4] in fp8, on the fixture the 16-bit modes pass above.  MEASURED: the
+    e4m3 configuration does NOT keep the fp32 top-5 on c5_sep — |dlogit| 0.57-0.68 against a logit std of 0.15-0.20, rank
+    correlation 0.44-0.64, top-5 overlap 0-1 of 5, with the 16-bit FFN-down as with the e4m3 one.  A widened random network
+    amplifies a perturbation layer by layer (its fp16 drift is already 10 x that of c5_full); the 3-bit mantissa of e4m3 perturbs
+    every GEMM at the 1e-3 level and 25 layers later the ranking is gone.  Hence: rr_config.fp8 is an opt-in whose drift bench.py
+    and DESIGN.md report, "fp8_ffn_down" is off by default, and no further speed is bought with e4m3 until a trained checkpoint
+    says otherwise.  The test records the outcome and is an EXPECTED failure; it turns into XPASS if a change makes fp8 rank."""
     import rmr_amd
-    from helpers import O, arch_from_cfg, load_fullsize, margin_stats, record_margin
+    from helpers import arch_from_cfg, load_fullsize
     cfg, w, vision, qs = load_fullsize("c5_sep")
-    results = {}
-    for mode in ("fp16", "fp8"):
-        arch = arch_from_cfg(cfg, vision, "fp16")
-        arch["fp8"] = int(mode == "fp8")
-        eng = rmr_amd.RerankEngine(arch)
-        eng.load_state_dict(w)
-        if mode == "fp8":
-            eng.set_option("fp8_ffn_down", down)
-        elif down:
-            continue                                           # the 16-bit control runs once (down = 0)
-        ranked, ranked_ref, pos, ok_sets = [], [], [], []
-        for qi, q in enumerate(qs):
-            sel = torch.from_numpy(q["selected"].astype(np.int64))
-            ids, am, tt = q["ids"][sel], q["am"][sel], q["tt"][sel]
-            r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), 1, len(sel), want_order=True)
-            torch.cuda.synchronize()
-            lg, ref = r["logits"].cpu(), q["fp32"][sel]
-            order, ref_order = r["order"][0].cpu().tolist(), O.rank_descending_stable(ref.tolist())
-            st = margin_stats(lg, ref)
-            gap = float(q["gap_5_6"])
-            ok = set(order[:5]) == set(ref_order[:5])
-            print(f"[c5_sep/{mode} down={down} q{qi}] |dlogit| {st['max_abs']:.3e} centred {st['centred']:.3e} rho {st['rho']:.4f} "
-                  f"top-5 {st['top5']}; logit std {ref.std():.3f}, rank-5/6 gap {gap:.3f}; top-5 set {'kept' if ok else 'LOST'}")
-            record_margin(f"c5_sep/q{qi}/{mode}" + (f"/ffn_down_{'e4m3' if down else '16bit'}" if mode == "fp8" else ""),
-                          gap_5_6=gap, top5_set_kept=bool(ok), **st)
-            assert torch.isfinite(lg).all() and order == O.rank_descending_stable(lg.tolist())
-            ranked.append(order); ranked_ref.append(ref_order); pos.append([int(q["positive_list_index"])]); ok_sets.append(ok)
-        got = rmr_amd.recall_precision_at_k(ranked, pos, [5, 10])
-        want = O.recall_precision_at_k(ranked_ref, pos, [5, 10])
-        results[mode] = (ok_sets, got, want)
-        del eng
-        torch.cuda.empty_cache()
-    for mode, (ok_sets, got, want) in results.items():
-        assert want["recall"] == [0.5, 1.0]
-        assert all(ok_sets), f"{mode} (fp8_ffn_down={down}): top-5 set differs from the fp32 reference's"
-        assert got == want, f"{mode} (fp8_ffn_down={down}): Recall@5/10 {got} != {want}"
+    arch = arch_from_cfg(cfg, vision, "fp16")
+    arch["fp8"] = 1
+    eng = rmr_amd.RerankEngine(arch)
+    eng.load_state_dict(w)
+    eng.set_option("fp8_ffn_down", down)
+    kept, got, want = _rank_c5_sep(eng, qs, "fp8/ffn_down_" + ("e4m3" if down else "16bit"))
+    if not (all(kept) and got == want):
+        pytest.xfail(f"fp8 (fp8_ffn_down={down}) loses the fp32 top-5 on c5_sep: sets kept {kept}, Recall@5/10 {got['recall']} vs {want['recall']}")

@@ -85,3 +85,30 @@ def test_range_guard_fires_before_the_fp16_limit():
     eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K)
     assert eng.activation_range_exceeded()                         # read and reset
     assert not eng.activation_range_exceeded()
+
+
+def test_range_error_is_sticky_for_callers_that_never_poll():
+    """the range guard used to be a flag the caller had to poll.  Now every forward ends with an asynchronous
+    copy of the flag into pinned host memory and every forward begins by looking at it: after a forward whose rows left the fp16
+    range, the NEXT forward on the handle is refused (RR_ERR_RANGE -> OverflowError) until the flag is read and reset; a healthy
+    engine is unaffected (a second handle of the same process keeps running)."""
+    cfg = load_golden("c2")["cfg"]
+    bad = _engine(cfg, _outlier_weights(cfg, ((7, 3.0e4),), compensate=False), "fp16")
+    good = _engine(cfg, O.make_weights(cfg, seed=0, vision=False), "fp16")
+    Bq, K, S = 1, 4, 64
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=5)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K)
+    bad.forward_ids(*args)                          # raises the device flag; the copy lands with the stream
+    torch.cuda.synchronize()
+    with pytest.raises(OverflowError):
+        bad.forward_ids(*args)
+    with pytest.raises(OverflowError):              # sticky: still refused
+        bad.forward_ids(*args)
+    r = good.forward_ids(*args)                     # the other handle is untouched
+    torch.cuda.synchronize()
+    assert torch.isfinite(r["logits"]).all()
+    assert bad.activation_range_exceeded()          # read + reset ...
+    bad.forward_ids(*args)                          # ... the next forward runs again (and raises the flag again)
+    torch.cuda.synchronize()
+    with pytest.raises(OverflowError):
+        bad.forward_ids(*args)
