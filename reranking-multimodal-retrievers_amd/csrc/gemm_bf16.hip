@@ -52,8 +52,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else static_assert(N < 0, "add the vmcnt literal");
 }
@@ -1541,356 +1539,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 }
 
 
-// Variant HQ ("persistent ring, direct epilogue"): the main loop of gemm_kernel_hp, 16-bit output forms only, with the epilogue
-// taken STRAIGHT from the accumulators: no staging image, no epilogue barrier, no LDS traffic beyond the parameter reads.
-//   * The weight rows of a tile are placed in the LDS image in a permuted order (a per-lane SOURCE address of the LDS-DMA, so
-//     it costs nothing): MFMA row index i of column block nt holds real column (i >> 2) * 8 + nt * 4 + (i & 3) of the wave's
-//     32-column block.  A lane then owns EIGHT consecutive output columns of a row across its two column blocks, i.e. one
-//     16-byte store per (quadrant, row block): 16 store instructions per wave and tile (each 16 rows x 64 B) instead of 64 KiB
-//     of staging writes + reads + two barriers per pass.
-//   * Nothing of the epilogue lives in LDS, so ALL EIGHT half-tiles of the next tile's K-tiles 0 and 1 are requested before the
-//     epilogue starts (hp: five, the rest behind the staging image), the parameter block is double-buffered, and the stores
-//     drain under the next tile's main loop: its first K-tile waits with literals that leave the 16 stores outstanding
-//     (vmcnt counts loads, LDS-DMA and stores together, in issue order).
-// Same products, same fp32 accumulation order per element, same epilogue arithmetic as hp: bit-identical output.
-template <int EPI, int DT, bool FOLD, bool DIAG = false>
-__global__ __launch_bounds__(512) void gemm_kernel_hq(const bf16_t* __restrict__ A, int lda,
-                                                     const bf16_t* __restrict__ W, int ldw,
-                                                     const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc,
-                                                     int M, int N, int Kd, int tiles_n, int nwg,
-                                                     unsigned long long* stamps, const float2* __restrict__ in_stats,
-                                                     const float* __restrict__ csum, int stagger_unit) {
-  static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_TANH_BF16 || EPI == EPI_BIAS_QGELU_BF16,
-                "16-bit output forms only");
-  const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50)) : (stagger_unit == 56 || Kd > 1024) ? 1 : 8;
-  constexpr int BM = 256, BN = 256, HALF = 128 * 128;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  const int bid = blockIdx.x, gstep = (int)(gridDim.x >> 3);
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, chunk_n = q8 + (xcd < r8 ? 1 : 0);
-  int li = bid >> 3;
-  if (li >= chunk_n) return;
-  int m0, n0;
-  const int tiles_m = nwg / tiles_n;
-  auto tile_origin = [&](int gidx, int& m0_, int& n0_) {
-    const int per_group = GROUP * tiles_n, grp = gidx / per_group, r = gidx - grp * per_group;
-    const int rows = min(GROUP, tiles_m - grp * GROUP);
-    const int tn = r / rows, tm = grp * GROUP + (r - tn * rows);
-    m0_ = tm * BM;
-    n0_ = tn * BN;
-  };
-  tile_origin(chunk0 + li, m0, n0);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  // ---- DMA sources as in hp, except that LDS row r of a weight half-tile is fed from weight row perm(r) (above)
-  uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
-  const bf16_t *a_tile, *w_tile;
-#define RQ_SETUP_SRC(m0_, n0_)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-    const int r = (wave * 2 + i) * 8 + (lane >> 3);          /* LDS row inside the half-tile */         \
-    const int c = (lane & 7) ^ ((r >> 1) & 7);                                                          \
-    const int rp = (r & ~31) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);                  \
-    so_a0[i] = (uint32_t)(((size_t)min(r, M - 1 - (m0_)) * lda + c * 8) * 2);                           \
-    so_a1[i] = (uint32_t)(((size_t)min(128 + r, M - 1 - (m0_)) * lda + c * 8) * 2);                     \
-    so_b0[i] = (uint32_t)(((size_t)min(rp, N - 1 - (n0_)) * ldw + c * 8) * 2);                          \
-    so_b1[i] = (uint32_t)(((size_t)min(128 + rp, N - 1 - (n0_)) * ldw + c * 8) * 2);                    \
-  }                                                                                                     \
-  a_tile = A + (size_t)(m0_) * lda;                                                                     \
-  w_tile = W + (size_t)(n0_) * ldw;
-  RQ_SETUP_SRC(m0, n0)
-  const uint32_t lds_base = lds_addr(lds);
-  const int nk = Kd / BK, H = 4 * nk;
-#define RQ_DMA(t_, J)                                                                                             \
-  {                                                                                                               \
-    const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
-    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)(t_) * BK) : (const void*)(w_tile + (size_t)(t_) * BK); \
-    const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
-    glds16_so(sb_, so_[0], dst_);                                                                                 \
-    glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
-  }
-  auto wait_half = [&](int h_need, int h_last) {
-    if (h_need >= H) return;
-    const int after = h_last - h_need;
-    if (after >= 3) wait_vmcnt<6>();
-    else if (after == 2) wait_vmcnt<4>();
-    else if (after == 1) wait_vmcnt<2>();
-    else wait_vmcnt<0>();
-  };
-
-  const int a_off = swz128(wr * 64 + (lane & 15), lane >> 4);
-  const int b_off = swz128(wc * 32 + (lane & 15), lane >> 4);
-  auto read_a = [&](const char* slot, int ks, bf16x8 (&f)[4]) {
-    const char* b = slot + (ks ? (a_off ^ 64) : a_off);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) f[mt] = *(const bf16x8*)(b + mt * 2048);
-  };
-  auto read_b = [&](const char* slot, int ks, bf16x8 (&f)[2]) {
-    const char* b = slot + (ks ? (b_off ^ 64) : b_off);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) f[nt] = *(const bf16x8*)(b + nt * 2048);
-  };
-
-  // acc[q = 2*hA+hB][nt][mt]; lane: row hA*128 + wr*64 + mt*16 + (lane&15), column hB*128 + wc*32 + (lane>>4)*8 + nt*4 + reg
-  f32x4 acc[4][2][4];
-  bf16x8 AF0[4], AF1[4], B0K0[2], B0K1[2], B1K0[2], B1K1[2];
-
-#define RQ_BLK(Q, AF, BF)                                                                          \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
-      acc[Q][nt][mt] = mfma16<DT>(BF[nt], AF[mt], acc[Q][nt][mt]);
-#define RQ_SBAR() __builtin_amdgcn_sched_barrier(0)
-#define RQ_PRIO(p) __builtin_amdgcn_s_setprio(p);
-
-  // Epilogue parameters through LDS as in hp ((mean, rstd) of the tile's 256 rows, bias and column sums of its 256 columns,
-  // in natural column order), in TWO 4-KiB buffers at [152 KiB, 160 KiB): the next tile's block is requested while this tile's
-  // is still being read.  Layout per buffer: +0 stats[256] float2, +2048 bias[256], +3072 csum[256].
-  constexpr int PARAM_OFF = 152 * 1024;
-  auto stage_params = [&](int m0_, int n0_, int buf) {
-    int lane_ = lane;
-    asm volatile("" : "+v"(lane_));
-    const int lane = lane_;
-    const uint32_t pb = lds_base + PARAM_OFF + buf * 4096;
-    if constexpr (FOLD) {
-      const int d = wave * 64 + lane;
-      glds4_so(in_stats + m0_, (uint32_t)((min(d >> 1, M - 1 - m0_) * 2 + (d & 1)) * 4), __builtin_amdgcn_readfirstlane(pb + wave * 256));
-    }
-    if (wave < 4) {
-      if (bias) glds4_so(bias + n0_, (uint32_t)(min(wave * 64 + lane, N - 1 - n0_) * 4), __builtin_amdgcn_readfirstlane(pb + 2048 + wave * 256));
-    } else if (FOLD) {
-      glds4_so(csum + n0_, (uint32_t)(min((wave - 4) * 64 + lane, N - 1 - n0_) * 4), __builtin_amdgcn_readfirstlane(pb + 3072 + (wave - 4) * 256));
-    }
-  };
-  if (!bias) {          // no bias vector: both blocks read as zeros for the whole launch (visible after the first tile's barrier)
-    if (tid < 256) { *(float*)(lds + PARAM_OFF + 2048 + tid * 4) = 0.f; *(float*)(lds + PARAM_OFF + 4096 + 2048 + tid * 4) = 0.f; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  // ---- first output tile: cold prologue.  Queue: [params][g0 .. g7], g = 4 * K-tile + {A0:0, B0:1, B1:2, A1:3}
-  int pbuf = 0;
-  stage_params(m0, n0, pbuf);
-  RQ_DMA(0, 0) RQ_DMA(0, 1) RQ_DMA(0, 2) RQ_DMA(0, 3)
-  RQ_DMA(1, 0) RQ_DMA(1, 1) RQ_DMA(1, 2) RQ_DMA(1, 3)
-  // `relaxed`: this tile's first K-tile may leave the previous tile's 16 epilogue stores outstanding (they sit between the
-  // prefetched g0 .. g7 and this tile's refills in the queue).  Only when that tile issued EXACTLY 16 stores per wave (a full
-  // tile: no exec-masked store that the compiler may branch around); otherwise the store-free literals.
-  bool relaxed = false;
-  unsigned long long ep[6] = {0, 0, 0, 0, 0, 0}, em0 = 0, em1 = 0;
-#define EQ_MARK(var) { if constexpr (DIAG) { RQ_SBAR(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); RQ_SBAR(); } }
-#define EQ_ADD(slot) { if constexpr (DIAG) { EQ_MARK(em1) ep[slot] += em1 - em0; em0 = em1; } }
-  EQ_MARK(em0)
-  for (;;) {                                                // one iteration per output tile of this workgroup
-  // K-tile 0 (g0 .. g3) landed: younger in the queue are g4 .. g7 (8 pieces) [+ params + 16 stores]
-  if (relaxed) wait_vmcnt<24>(); else wait_vmcnt<8>();
-  __builtin_amdgcn_s_barrier();
-  EQ_ADD(4)
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  read_a(lds + 0 * HALF, 0, AF0);
-  read_b(lds + 1 * HALF, 0, B0K0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1]));
-
-  // sync point.  FIRSTK (K-tile 0 of an output tile): X needs g5, younger are g6, g7 [+ params + stores]; Y needs g7, younger
-  // are g8, g9, g10 [+ params + stores].  STEADY: literals 4 / 6 as in hp.  Otherwise the guarded tail.
-#define RQ_SYNC(STEADY, FIRSTK, NLIT, NREL, g_need, g_last)  \
-  {                                                      \
-    RQ_SBAR();                                           \
-    if (FIRSTK) { if (relaxed) wait_vmcnt<NREL>(); else wait_vmcnt<NLIT>(); } \
-    else if (STEADY) wait_vmcnt<NLIT>();                 \
-    else wait_half(g_need, g_last);                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-    __builtin_amdgcn_s_barrier();                        \
-    RQ_SBAR();                                           \
-  }
-  // The K-tile of hp (two barriers, refills p0 A1(t+1); p2 A0(t+2), B0(t+2); p3 B1(t+2)); FIRSTK: A1(1) was prefetched with
-  // the rest of K-tile 1, so p0 issues nothing.
-#define RQ_TILE(STEADY, FIRSTK)                                                                            \
-  {                                                                                                        \
-    const char* sl = lds + (t & 1) * 4 * HALF;                                                             \
-    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;                                                       \
-    const bool d1 = ((STEADY) || t + 1 < nk), d2 = ((STEADY) || t + 2 < nk);                                \
-    /* ---- p0: quadrant (A0, B0) */                                                                        \
-    read_a(sl + 0 * HALF, 1, AF1);                                                                         \
-    read_b(sl + 1 * HALF, 1, B0K1);                                                                        \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(3)                                                                                             \
-    RQ_BLK(0, AF0, B0K0)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    read_b(sl + 2 * HALF, 0, B1K0);                                                                        \
-    if (!(FIRSTK) && d1) RQ_DMA(t + 1, 3)                                                                  \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(2)                                                                                             \
-    RQ_BLK(0, AF1, B0K1)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    /* ---- p1: quadrant (A0, B1) */                                                                        \
-    read_b(sl + 2 * HALF, 1, B1K1);                                                                        \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(1)                                                                                             \
-    RQ_BLK(1, AF0, B1K0)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    read_a(sl + 3 * HALF, 0, AF0);                                                                         \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(0)                                                                                             \
-    RQ_BLK(1, AF1, B1K1)                                                                                   \
-    RQ_SYNC(STEADY, FIRSTK, 4, 20, 4 * (t + 1) + 1, min(H - 1, 4 * (t + 1) + 3))   /* X: A0(t+1), B0(t+1) landed */ \
-    /* ---- p2: quadrant (A1, B1) */                                                                        \
-    read_a(sl + 3 * HALF, 1, AF1);                                                                         \
-    if (d2) RQ_DMA(t + 2, 0)                                                                               \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(3)                                                                                             \
-    RQ_BLK(3, AF0, B1K0)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    if (d2) RQ_DMA(t + 2, 1)                                                                               \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(2)                                                                                             \
-    RQ_BLK(3, AF1, B1K1)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    /* ---- p3: quadrant (A1, B0) */                                                                        \
-    RQ_PRIO(1)                                                                                             \
-    RQ_BLK(2, AF0, B0K0)                                                                                   \
-    RQ_SBAR();                                                                                             \
-    if ((STEADY) || t + 1 < nk) {                                                                          \
-      read_a(sn + 0 * HALF, 0, AF0);                                                                       \
-      read_b(sn + 1 * HALF, 0, B0K0);                                                                      \
-    }                                                                                                      \
-    if (d2) RQ_DMA(t + 2, 2)                                                                               \
-    RQ_SBAR();                                                                                             \
-    RQ_PRIO(0)                                                                                             \
-    RQ_BLK(2, AF1, B0K1)                                                                                   \
-    RQ_SYNC(STEADY, FIRSTK, 6, 22, 4 * (t + 1) + 3, min(H - 1, 4 * (t + 2) + 2))   /* Y: B1(t+1), A1(t+1) landed */ \
-    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1])); \
-  }
-  int t = 0;
-  RQ_TILE(1, 1)                                             // nk >= 3 (host): every refill of K-tile 0 exists
-  for (t = 1; t < nk - 2; ++t) RQ_TILE(1, 0)
-  for (; t < nk; ++t) RQ_TILE(0, 0)
-#undef RQ_TILE
-#undef RQ_SYNC
-  wait_vmcnt<0>();   // every half-tile was waited for; the previous tile's stores completed long ago (strict literals from K-tile 1 on)
-  EQ_ADD(0)
-
-  // ---- next output tile of this workgroup: all of its K-tiles 0 and 1 into the (free) ring, its parameters into the other block
-  const int cm0 = m0, cn0 = n0;                             // the tile being written out
-  li += gstep;
-  const bool has_next = li < chunk_n;
-  if (has_next) {
-    tile_origin(chunk0 + li, m0, n0);
-    RQ_SETUP_SRC(m0, n0)
-    RQ_DMA(0, 0) RQ_DMA(0, 1) RQ_DMA(0, 2) RQ_DMA(0, 3)
-    RQ_DMA(1, 0) RQ_DMA(1, 1) RQ_DMA(1, 2) RQ_DMA(1, 3)
-    stage_params(m0, n0, pbuf ^ 1);
-  }
-  EQ_ADD(1)
-
-  // ---- epilogue of tile (cm0, cn0), from the accumulators
-  {
-    int lane_o_ = lane;
-    asm volatile("" : "+v"(lane_o_));      // opaque: per-lane offsets are recomputed per tile, not hoisted across the main loop and spilled
-    const int l15 = lane_o_ & 15, lg = lane_o_ >> 4;
-    auto activate = [&](f32x4 ab) -> f32x4 {
-      float v0 = ab[0], v1 = ab[1], v2 = ab[2], v3 = ab[3];
-      if constexpr (EPI == EPI_BIAS_GELU_BF16 && RR_PK_GELU != 0) {
-        const f32x2 g0 = gelu_erf_fast2(f32x2{v0, v1}), g1 = gelu_erf_fast2(f32x2{v2, v3});
-        return f32x4{g0.x, g0.y, g1.x, g1.y};
-      }
-      if (EPI == EPI_BIAS_GELU_BF16) { v0 = gelu_fast(v0); v1 = gelu_fast(v1); v2 = gelu_fast(v2); v3 = gelu_fast(v3); }
-      if (EPI == EPI_BIAS_TANH_BF16) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
-      if (EPI == EPI_BIAS_QGELU_BF16) { v0 = qgelu_fast(v0); v1 = qgelu_fast(v1); v2 = qgelu_fast(v2); v3 = qgelu_fast(v3); }
-      return f32x4{v0, v1, v2, v3};
-    };
-    const char* const pblk = lds + PARAM_OFF + pbuf * 4096;
-    const char* const pcol = pblk + 2048 + (wc * 32 + lg * 8) * 4;     // bias of this lane's columns (hB = 0, nt = 0); csum at +1024
-    // parameter reads one (quadrant, column block) step ahead of the arithmetic, as in hp
-    if constexpr (FOLD) {
-      float2 fst[2][4];
-#pragma unroll
-      for (int hA = 0; hA < 2; ++hA)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          fst[hA][mt] = *(const float2*)(pblk + (hA * 128 + wr * 64 + mt * 16 + l15) * 8);
-      float4 bv_n = *(const float4*)(pcol), cs_n = *(const float4*)(pcol + 1024);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int q = it >> 1, nt = it & 1;
-        const float4 bv = bv_n, cs = cs_n;
-        if (it + 1 < 8) {
-          const int o = ((((it + 1) >> 1) & 1) * 128 + ((it + 1) & 1) * 4) * 4;
-          bv_n = *(const float4*)(pcol + o);
-          cs_n = *(const float4*)(pcol + 1024 + o);
-        }
-        RQ_SBAR();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[q][nt][mt] = activate(fold_apply(acc[q][nt][mt], fst[q >> 1][mt], cs, bv));
-        RQ_SBAR();
-      }
-    } else {
-      float4 bv_n = *(const float4*)(pcol);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int q = it >> 1, nt = it & 1;
-        const float4 bv = bv_n;
-        if (it + 1 < 8) bv_n = *(const float4*)(pcol + ((((it + 1) >> 1) & 1) * 128 + ((it + 1) & 1) * 4) * 4);
-        RQ_SBAR();
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[q][nt][mt] = activate(f32x4{acc[q][nt][mt][0] + bv.x, acc[q][nt][mt][1] + bv.y, acc[q][nt][mt][2] + bv.z, acc[q][nt][mt][3] + bv.w});
-        RQ_SBAR();
-      }
-    }
-    EQ_ADD(2)
-    // 16 stores of 16 bytes per lane: (quadrant, row block) -> row cm0 + hA*128 + wr*64 + mt*16 + l15, columns cn0 + hB*128 + wc*32 + lg*8 .. +7
-    const bool full = cm0 + BM <= M && cn0 + BN <= N;
-    bf16_t* const crow = C + (size_t)(cm0 + wr * 64 + l15) * ldc + (cn0 + wc * 32 + lg * 8);
-    auto packed = [&](int q, int mt) {
-      return make_uint4(pack2<DT>(acc[q][0][mt][0], acc[q][0][mt][1]), pack2<DT>(acc[q][0][mt][2], acc[q][0][mt][3]),
-                        pack2<DT>(acc[q][1][mt][0], acc[q][1][mt][1]), pack2<DT>(acc[q][1][mt][2], acc[q][1][mt][3]));
-    };
-    if (full) {          // every lane stores: exactly 16 store instructions per wave, no exec masking (what `relaxed` counts on)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          store_stream(crow + (size_t)((q >> 1) * 128 + mt * 16) * ldc + (q & 1) * 128, packed(q, mt));
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int hA = q >> 1, hB = q & 1;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          if (cm0 + hA * 128 + wr * 64 + mt * 16 + l15 < M && cn0 + hB * 128 + wc * 32 + lg * 8 < N)
-            store_stream(crow + (size_t)(hA * 128 + mt * 16) * ldc + hB * 128, packed(q, mt));
-      }
-    }
-    relaxed = full;
-    EQ_ADD(3)
-  }
-  if constexpr (DIAG) ep[5] += 1;
-  if (!has_next) break;
-  pbuf ^= 1;
-  }   // output tiles
-  if constexpr (DIAG) {
-    if (stamps && lane == 0) {
-      unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-      for (int k = 0; k < 6; ++k) o[k] = ep[k];
-    }
-  }
-#undef EQ_MARK
-#undef EQ_ADD
-#undef RQ_SETUP_SRC
-#undef RQ_DMA
-#undef RQ_BLK
-#undef RQ_SBAR
-#undef RQ_PRIO
-}
-
-
-
 
 unsigned long long* g_stamps = nullptr;   // diagnostic only (rr_set_gemm_stamps)
 std::atomic<int> g_resid_touch{0};       // rr_set_tuning("resid_touch"): L2 touch of the next pass's residual rows; off since the rows themselves are requested a pass ahead (r03: 100.8 -> 99.8 ms)
@@ -2016,51 +1664,6 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   return hipGetLastError();
 }
 
-// persistent ring with the direct epilogue (variant 16; the default for the 16-bit output forms of large problems,
-// rr_set_tuning "gemm_direct"): same grid and LDS as launch_hp
-std::atomic<int> g_direct{0};     // measured slower than the staged epilogue (profiles/r04_a_*): off
-inline bool hq_eligible(int M, int N, int Kd, int epilogue, const LnResid& ln) {
-  if (epilogue != EPI_BIAS_BF16 && epilogue != EPI_BIAS_GELU_BF16) return false;
-  if (ln.x16 || ln.r_hi || ln.lo_out || ln.stats) return false;
-  return !(N & 7) && Kd / BK >= 3;
-}
-template <int DT>
-hipError_t launch_hq(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
-                     int Kd, int epilogue, hipStream_t st, LnResid ln) {
-  if (!hq_eligible(M, N, Kd, epilogue, ln)) return hipErrorInvalidValue;
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
-  const int n_cu = device_cus();
-  if (n_cu < 8) return hipErrorInvalidValue;
-  constexpr int lds_bytes = 160 * 1024;
-  dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
-  const bool diag = g_stamps != nullptr && g_variant.load() == 17;
-#define RR_HQ_CASE(E, F, D)                                                                                   \
-  {                                                                                                           \
-    auto kern = gemm_kernel_hq<E, DT, F, D>;                                                                  \
-    static std::atomic<unsigned long long> attr_mask{0};                                                      \
-    {                                                                                                         \
-      hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                                \
-      if (e != hipSuccess) return e;                                                                          \
-    }                                                                                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, (bf16_t*)C, ldc, M, N, Kd,     \
-                       tiles_n, nwg, g_stamps, ln.in_stats, ln.csum,                                          \
-                       (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : 0);                                 \
-    return hipGetLastError();                                                                                 \
-  }
-  if (diag) {      // tools/gemm_epilogue_timeline.py --direct: the two production forms
-    if (epilogue == EPI_BIAS_BF16 && ln.in_stats) RR_HQ_CASE(EPI_BIAS_BF16, true, true)
-    if (epilogue == EPI_BIAS_GELU_BF16 && ln.in_stats) RR_HQ_CASE(EPI_BIAS_GELU_BF16, true, true)
-    return hipErrorInvalidValue;
-  }
-  if (epilogue == EPI_BIAS_BF16) {
-    if (ln.in_stats) RR_HQ_CASE(EPI_BIAS_BF16, true, false)
-    RR_HQ_CASE(EPI_BIAS_BF16, false, false)
-  }
-  if (ln.in_stats) RR_HQ_CASE(EPI_BIAS_GELU_BF16, true, false)
-  RR_HQ_CASE(EPI_BIAS_GELU_BF16, false, false)
-#undef RR_HQ_CASE
-}
-
 // diagnostic build of the persistent kernel (variant 15, tools/bench_gemm.py --epilogue-timeline): the production forms only
 template <int DT>
 hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const float* resid,
@@ -2184,7 +1787,7 @@ hipError_t launch_cfg(const bf16_t* A, int lda, const bf16_t* W, int ldw, const 
 
 // tuning hook (tools/bench_gemm.py): -1 = shape heuristic
 extern "C" int rr_set_gemm_variant(int v) {
-  if (v < -1 || v > 17) return -1;
+  if (v < -1 || v > 15) return -1;
   g_variant.store(v);
   return 0;
 }
@@ -2202,7 +1805,6 @@ extern "C" int rr_set_gemm_desync(int pct) {
   return 0;
 }
 extern "C" int rr_set_resid_fast(int on) { g_resid_fast.store(on != 0); return 0; }
-extern "C" int rr_set_gemm_direct(int on) { g_direct.store(on != 0); return 0; }
 extern "C" int rr_set_gemm_stagger(int unit) {
   if (unit < 0 || unit > 64) return -1;
   g_stagger = unit;
@@ -2227,7 +1829,7 @@ extern "C" int rr_get_resid_split(void) { return g_resid_split.load(); }
 // is available (every residual GEMM of a stack has the same M x N, so the answer holds for producer and consumer alike).
 bool rr_gemm_split_ok(int M, int N) {
   static const bool env_variant = getenv("RR_GEMM_VARIANT") != nullptr;     // read once: an environment override pins a kernel
-  if ((g_variant.load() >= 0 && g_variant.load() < 15) || !g_persistent || env_variant) return false;   // ("resid_split" on / off is the caller's: a handle option)
+  if ((g_variant.load() >= 0 && g_variant.load() != 15) || !g_persistent || env_variant) return false;   // ("resid_split" on / off is the caller's: a handle option)
   return (long)((M + 255) / 256) * ((N + 255) / 256) >= g_ring_min_tiles.load() && !(N & 7);
 }
 
@@ -2277,21 +1879,11 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     v = tiles256 >= g_ring_min_tiles.load() ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
   }
-  // 16-bit output forms of the persistent ring: the direct epilogue (gemm_kernel_hq) unless switched off; 16 / 17 force it
-  // (17: its diagnostic build) and fall back to the staged kernel for the forms it does not implement
-  {
-    const bool hq_ok = hq_eligible(M, N, Kd, epilogue, ln);
-    if (v == 16 || v == 17) { if (!hq_ok) v = 14; }
-    else if (v == 14 && g_variant.load() < 0 && g_direct.load() && hq_ok) v = 16;   // (a forced 14 stays the staged kernel)
-  }
   if (fold.x16) {   // the producer side of the folded LayerNorm lives in the LDS-staged epilogues only
     if (v == 0) v = 20;
     else if (v != 10 && v != 12 && v != 14 && v != 15 && v != 20) return hipErrorInvalidValue;
   }
   if (split && v != 14 && v != 15) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
-  if (v == 16 || v == 17)
-    return dt == 1 ? launch_hq<1>(A, lda, W, ldw, bias, C, ldc, M, N, Kd, epilogue, st, ln)
-                   : launch_hq<0>(A, lda, W, ldw, bias, C, ldc, M, N, Kd, epilogue, st, ln);
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
       case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);

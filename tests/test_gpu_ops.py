@@ -429,7 +429,7 @@ def test_fp16_operand_ops(lib):
 
 # ---- every tile configuration behind rr_set_gemm_variant, the production half-tile-ring kernel (11 direct / 12 LDS
 # epilogue) included: the shape heuristic only picks it at >= 512 output tiles, so it is forced here on ragged shapes
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 10, 11, 12, 14, 16])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 10, 11, 12, 14])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_variant_every_epilogue(lib, variant, epi):
     shapes = [(1000, 768, 768), (515, 2304, 768), (257, 200, 3072), (64, 64, 64)]
@@ -531,7 +531,7 @@ def test_ln_residual_gemm_is_reproducible_and_matches_materialised_residual(lib,
         lib.rr_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [12, 14, 16])
+@pytest.mark.parametrize("variant", [12, 14])
 @pytest.mark.parametrize("M,N,K", [(70001, 1000, 128), (33 * 256 + 5, 2304, 64), (256 * 300, 768, 192), (65537, 264, 320)])
 def test_ring_kernels_ragged_multi_tile(lib, variant, M, N, K):
     """The ring kernels at sizes where a persistent workgroup walks several tiles, with ragged last row/column tiles and
@@ -556,49 +556,6 @@ def test_ring_kernels_ragged_multi_tile(lib, variant, M, N, K):
     assert torch.isfinite(out16.float()).all() and (e16 <= 1.2e-2 * (1 + ref.abs())).all(), e16.max().item()
     e32 = (out32 - (ref + R)).abs()
     assert torch.isfinite(out32).all() and (e32 <= 2e-4 * (1 + ref.abs())).all(), e32.max().item()
-
-
-@pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("N,K,epi", [(2304, 768, 0), (3072, 768, 1), (1536, 768, 0), (1024, 4096, 1)])
-def test_direct_epilogue_kernel_equals_staged_kernel_bit_for_bit(lib, dt, N, K, epi):
-    """gemm_kernel_hq (variant 16: weight rows permuted inside the LDS image, 16-byte stores straight from the accumulators, the
-    stores left in flight under the next tile's first K-tile) against gemm_kernel_hp (variant 14: LDS-staged epilogue) on the
-    production forms — plain bias and folded LayerNorm, 16-bit and GELU — at a size where every workgroup walks several tiles
-    and the last row tile is ragged (its waves issue fewer stores: the strict wait literals must take over).  Same products,
-    same accumulation order, same epilogue arithmetic: every bit equal, and equal run to run."""
-    M = 256 * 190 + 77
-    g = torch.Generator(device="cpu").manual_seed(N + K + epi)
-    cast = (lambda t: t.half()) if dt else (lambda t: t.bfloat16())
-    A = cast(torch.randn(M, K, generator=g) * 0.5).cuda()
-    W = cast(torch.randn(N, K, generator=g) * 0.03).cuda()
-    b = torch.randn(N, generator=g).cuda()
-    csum = W.double().sum(1).float()
-    stats = torch.stack([torch.randn(M, generator=g) * 0.1, 1 + 0.2 * torch.rand(M, generator=g)], 1).cuda()
-    try:
-        assert lib.rr_set_op_dtype(dt) == 0
-        outs = {}
-        for variant in (14, 16, 16):
-            assert lib.rr_set_gemm_variant(variant) == 0
-            o1 = torch.full((M, N), float("nan"), device="cuda", dtype=A.dtype)
-            o2 = torch.full((M, N), float("nan"), device="cuda", dtype=A.dtype)
-            assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, epi, o1.data_ptr(), _stream()) == 0
-            assert lib.rr_op_gemm_lnfold(A.data_ptr(), W.data_ptr(), b.data_ptr(), csum.data_ptr(), stats.data_ptr(), M, N, K, epi,
-                                         o2.data_ptr(), _stream()) == 0
-            torch.cuda.synchronize()
-            assert torch.isfinite(o1.float()).all() and torch.isfinite(o2.float()).all()
-            if variant in outs:
-                assert torch.equal(_bits(o1), _bits(outs[variant][0])) and torch.equal(_bits(o2), _bits(outs[variant][1]))
-            outs[variant] = (o1, o2)
-        for k in (0, 1):
-            bad = (_bits(outs[14][k]) != _bits(outs[16][k])).nonzero()
-            assert len(bad) == 0, f"form {k}: {len(bad)} elements differ, first {bad[:4].tolist()}"
-        ref = A.float() @ W.float().t() + b
-        ref = _gelu(ref) if epi == 1 else ref
-        err = (outs[16][0].float() - ref).abs()
-        assert (err <= 1.2e-2 * (1 + ref.abs())).all(), err.max().item()
-    finally:
-        lib.rr_set_gemm_variant(-1)
-        lib.rr_set_op_dtype(0)
 
 
 @pytest.mark.parametrize("variant", [-1, 0])     # -1: the production heuristic (persistent ring), 0: the 128x128 kernel
