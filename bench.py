@@ -147,6 +147,22 @@ def archived_pmc():
             out["traffic_source"] = os.path.relpath(files[-1], ROOT)
         except Exception:
             pass
+    # the vendor library's GEMM at the path's shapes, measured beside this kernel's plain-epilogue form (tools/bench_vendor_gemm.py):
+    # what a library tile loop reaches at K = 768 / 3 072 on this chip — the yardstick for roofline.frac
+    files_v = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_vendor_gemm_yardstick.log")))
+    if files_v:
+        try:
+            import re
+            y = {}
+            for line in open(files_v[-1]):
+                mo = re.match(r"(\w+)\s+M=\d+ N=\d+ K=\d+ (\w+): ours: min [\d.]+ ms\s+([\d.]+) TF .*vendor: min [\d.]+ ms\s+([\d.]+) TF", line)
+                if mo and mo.group(2) == "fp16":
+                    y[mo.group(1)] = {"this_kernel_plain_epilogue_tflops": float(mo.group(3)), "vendor_gemm_no_epilogue_tflops": float(mo.group(4))}
+            if y:
+                out["vendor_gemm_yardstick_fp16"] = y
+                out["vendor_gemm_source"] = os.path.relpath(files_v[-1], ROOT)
+        except Exception:
+            pass
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")) if "_c5" not in os.path.basename(f))
     if files:
         try:
