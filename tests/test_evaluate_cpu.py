@@ -1,6 +1,7 @@
 """CPU: the batched executor-side loop, record schema and Recall@K bookkeeping (Reranker_base_executor.py:785-1030,
 metrics_processors.py:816-890) with a stand-in forward."""
 import json
+import os
 
 import pytest
 
@@ -62,3 +63,33 @@ def test_docs_to_rerank_must_equal_max_k():
     import rmr_amd
     with pytest.raises(AssertionError):
         rmr_amd.rerank_dataset([], lambda b: {}, 2, [5, 10], docs_to_rerank=100)
+
+
+def test_merge_margins_never_drops_a_key(tmp_path):
+    """tools/merge_margins.py (a one-test re-run had been copied over the full parity record): merging a
+    partial run refreshes its keys and keeps the others; --fresh with fewer keys and --check with a missing key are refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "merge_margins.py")
+    prof = os.path.join(root, "profiles", "rtest_parity_margins.json")
+    full = {"a/fp16": {"max_abs": 1e-4, "run": "r1"}, "b/fp16": {"max_abs": 2e-4, "run": "r1"}, "c/bf16": {"max_abs": 3e-3, "run": "r1"}}
+    part = {"b/fp16": {"max_abs": 2.5e-4, "run": "r2"}}
+    src_full, src_part, want = tmp_path / "full.json", tmp_path / "part.json", tmp_path / "want.json"
+    src_full.write_text(json.dumps(full)); src_part.write_text(json.dumps(part)); want.write_text(json.dumps(full))
+    try:
+        run = lambda *a: subprocess.run([sys.executable, tool, "rtest", *a], capture_output=True, text=True)
+        assert run("--src", str(src_full)).returncode == 0
+        assert run("--src", str(src_part)).returncode == 0                       # merge: refresh b, keep a and c
+        got = json.load(open(prof))
+        assert set(got) == set(full) and got["b/fp16"]["run"] == "r2" and got["a/fp16"]["run"] == "r1"
+        r = run("--src", str(src_part), "--fresh")                               # would drop a and c
+        assert r.returncode != 0 and "refused" in (r.stdout + r.stderr)
+        assert set(json.load(open(prof))) == set(full)                           # untouched
+        os.remove(prof)
+        r = run("--src", str(src_part), "--check", str(want))                    # a, c missing from the result
+        assert r.returncode != 0 and "refused" in (r.stdout + r.stderr)
+    finally:
+        if os.path.exists(prof):
+            os.remove(prof)
