@@ -381,8 +381,8 @@ def test_bert_large_shape_text_only():
     ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=21, regime="realistic")
     with torch.no_grad():
         ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K)
-    # measured (profiles/r03_parity_margins.json): fp16 9.9e-4 (|logit| up to 1.23, i.e. 8e-4 relative after 25 layers — the one
-    # case a hair under 1e-3, hence a gate of 1.3 x measured), bf16 5.1e-3 (gate 1.3 x)
+    # measured (profiles/r04_parity_margins.json): fp16 9.2e-4 (round 3: 9.9e-4; |logit| up to 1.23, i.e. 8e-4 relative after 25 layers — the one
+    # case a hair under 1e-3, hence a gate of 1.3e-3), bf16 5.5e-3 (gate 6.7e-3)
     for dtype, tol in (("fp16", 1.3e-3), ("bf16", 6.7e-3)):
         eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, False, dtype))
         eng.load_state_dict(w)
