@@ -896,6 +896,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // they span at most 256 row pitches, so A and W may be of any size.
   uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
   uint32_t woff[2][2];                                      // WREG: byte offset of this lane's weight fragment rows [hB][nt] from w_tile
+  const bool w_noload_ = WREG && stagger_unit == 61;        // diagnostic (wrong results): no weight loads
   const bf16_t *a_tile, *w_tile;
 #define RR_SETUP_SRC(m0_, n0_)                                                                          \
   int ls_ = lane;                                            /* WREG: opaque, so that the row indices below are recomputed per */ \
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #define RR_WLD(dst_, HB, KS, kt_)                                                                                   \
   {                                                                                                                 \
     const bf16_t* const wb_ = w_tile + (size_t)(kt_) * BK;                                                          \
-    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {                                                           \
+    if (!w_noload_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {                                           \
       if constexpr ((KS) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst_[0 + nt_]) : "v"(woff[HB][nt_]), "s"(wb_) : "memory"); \
       else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "+v"(dst_[2 + nt_]) : "v"(woff[HB][nt_]), "s"(wb_) : "memory"); \
     }                                                                                                               \
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // issue order): before a block that first uses a fragment pair of THIS K-tile, everything issued after that pair one K-tile
   // ago may still be outstanding — p0a 8, p0b 10, p1a 6, p1b 6, X (A0(t+1)) 10, Y (A1(t+1) = 1,2 of this K-tile) 10.  KIND 1 =
   // the last K-tile but one (no A0(t+2): Y 8), KIND 2 = the last (issues nothing: 6, 4, 2, 0).
-#define RR_WAITW(KIND, a_, b_, c_) { if constexpr ((KIND) == 0) wait_vmcnt<a_>(); else if constexpr ((KIND) == 1) wait_vmcnt<b_>(); else wait_vmcnt<c_>(); }
+#define RR_WAITW(KIND, a_, b_, c_) { if (!w_nowait) { if constexpr ((KIND) == 0) wait_vmcnt<a_>(); else if constexpr ((KIND) == 1) wait_vmcnt<b_>(); else wait_vmcnt<c_>(); } }
 #define RR_SYNCW(KIND, a_, b_, c_)                       \
   {                                                      \
     RR_SBAR();                                           \
@@ -1260,6 +1261,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     RR_SYNCW(KIND, 10, 8, 0)                                /* Y: A1(t+1) landed */                          \
     asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]));                             \
   }
+  // diagnostics (wrong results; rr_set_gemm_stagger 60 / 61): 60 = the counted waits in front of the MFMA blocks are skipped (what the
+  // weight loads' LATENCY costs), 61 = the weight loads themselves are skipped too (what their ISSUE costs; the rest is the LDS saving)
+  const bool w_nowait = WREG && (stagger_unit == 60 || stagger_unit == 61);
   int t = 0;
   if constexpr (WREG) {
     while (t < nk - 2) { RR_TILEW(0, W0a, W0b) ++t; RR_TILEW(0, W0b, W0a) ++t; }     // nk even (host)
@@ -1765,7 +1769,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
         if (e != hipSuccess) return e;                                                                        \
       }                                                                                                       \
       hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, \
-                         tiles_n, nwg, stamps, ln, desync);                                                   \
+                         tiles_n, nwg, stamps, ln, (g_stagger == 60 || g_stagger == 61) ? g_stagger : desync);    \
       return hipGetLastError();                                                                               \
     }
     if (ln.in_stats && !split && epilogue == EPI_BIAS_BF16) RR_LAUNCH_W(EPI_BIAS_BF16, 0, true)

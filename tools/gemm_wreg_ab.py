@@ -19,12 +19,14 @@ ap.add_argument("--pairs", type=int, default=800)
 ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--dtype", default="fp16")
 ap.add_argument("--shapes", default="qkv,attn_out,ffn1,ffn2")
+ap.add_argument("--stagger", type=int, default=0, help="60 / 61: diagnostic builds of the WREG loop (wrong results)")
 a = ap.parse_args()
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 M = a.pairs * 512
 dt = 1 if a.dtype == "fp16" else 0
 assert lib.rr_set_op_dtype(dt) == 0
+assert lib.rr_set_gemm_stagger(a.stagger) == 0
 cast = (lambda t: t.half()) if dt else (lambda t: t.bfloat16())
 g = torch.Generator().manual_seed(0)
 shapes = {"qkv": (2304, 768, "fold", 0), "attn_out": (768, 768, "split", 0), "ffn1": (3072, 768, "fold", 1), "ffn2": (768, 3072, "split", 0)}
@@ -79,4 +81,5 @@ for name in a.shapes.split(","):
         f"wreg={v}: min {min(t):.3f} ms {fl / min(t) / 1e9:7.1f} TF (med {sorted(t)[len(t) // 2]:.3f})" for v, t in res.items())
         + f"  | bitwise {'EQUAL' if same() else 'DIFFERENT'}", flush=True)
 lib.rr_set_tuning(b"gemm_wreg", 0)
+lib.rr_set_gemm_stagger(0)
 lib.rr_set_op_dtype(0)
