@@ -822,14 +822,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 // workgroup's tiles; 2 = also the 13 marks per K-tile of the main loop (they cost the loop ~11 %).  0 in every product launch.
 // FOLD: the folded-LayerNorm consumer form (ln.in_stats / ln.csum given) — a compile-time choice so that the accumulator
 // arithmetic is one straight-line block (as a run-time branch its two arms joined in 128 accumulator phis and spilled).
-// WREG (rr_set_tuning "gemm_wreg"): the WEIGHT operand goes L2 -> VGPR directly.  The weight is stored [N, K]
-// K-contiguous, which IS the MFMA fragment (16 rows x 8 elements per lane), so a wave's 64 weight columns of a K-tile are 8
-// global_load_dwordx4 (inline asm, "+v" destinations pinned for the whole loop, counted by hand in the same in-order vmcnt queue
-// as the LDS-DMA pieces), double-buffered in two register sets by K-tile parity (loaded one K-tile ahead: an L2 hit is 500-800
-// cycles away under load).  Only the activation half-tiles travel through the LDS ring: half the LDS-DMA writes and 8 of a
-// wave's 24 ds_read_b128 per K-tile disappear; the wave issues 12 instead of 8 vector-memory instructions per K-tile.  nk even.
-// Same products and accumulation order as the LDS form: bit-identical output.
-template <int EPI, int DT, int SPLIT = 0, int DIAG = 0, bool FOLD = false, bool WREG = false>
+template <int EPI, int DT, int SPLIT = 0, int DIAG = 0, bool FOLD = false>
 __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__ A, int lda,
                                                      const bf16_t* __restrict__ W, int ldw,
                                                      const float* __restrict__ bias,
@@ -895,23 +888,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // 32-bit byte offsets from the scalar origin of the CURRENT tile's rows (a_tile / w_tile, re-based per output tile):
   // they span at most 256 row pitches, so A and W may be of any size.
   uint32_t so_a0[2], so_a1[2], so_b0[2], so_b1[2];
-  uint32_t woff[2][2];                                      // WREG: byte offset of this lane's weight fragment rows [hB][nt] from w_tile
-  const bool w_noload_ = WREG && stagger_unit == 61;        // diagnostic (wrong results): no weight loads
   const bf16_t *a_tile, *w_tile;
 #define RR_SETUP_SRC(m0_, n0_)                                                                          \
-  int ls_ = lane;                                            /* WREG: opaque, so that the row indices below are recomputed per */ \
-  if constexpr (WREG) asm volatile("" : "+v"(ls_));          /* tile instead of hoisted out of the tile loop and spilled */    \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-    const int r = (wave * 2 + i) * 8 + (ls_ >> 3);           /* row inside the half-tile */             \
-    const int c = (ls_ & 7) ^ ((r >> 1) & 7);                                                           \
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);          /* row inside the half-tile */             \
+    const int c = (lane & 7) ^ ((r >> 1) & 7);                                                          \
     so_a0[i] = (uint32_t)(((size_t)min(r, M - 1 - (m0_)) * lda + c * 8) * 2);                           \
     so_a1[i] = (uint32_t)(((size_t)min(128 + r, M - 1 - (m0_)) * lda + c * 8) * 2);                     \
     so_b0[i] = (uint32_t)(((size_t)min(r, N - 1 - (n0_)) * ldw + c * 8) * 2);                           \
     so_b1[i] = (uint32_t)(((size_t)min(128 + r, N - 1 - (n0_)) * ldw + c * 8) * 2);                     \
-  }                                                                                                     \
-  if constexpr (WREG) {                                                                                 \
-    _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)  \
-      woff[hb_][nt_] = (uint32_t)(((size_t)min(hb_ * 128 + wc * 32 + nt_ * 16 + (ls_ & 15), N - 1 - (n0_)) * ldw + (ls_ >> 4) * 8) * 2); \
   }                                                                                                     \
   a_tile = A + (size_t)(m0_) * lda;                                                                     \
   w_tile = W + (size_t)(n0_) * ldw;
@@ -971,22 +956,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // k-step are fetched one 8-MFMA block ahead of their use, so nothing is double-buffered: 64 fragment + 128
   // accumulator registers.
   bf16x8 AF0[4], AF1[4], B0K0[2], B0K1[2], B1K0[2], B1K1[2];
-  // WREG: weight fragments in registers, index = kstep * 2 + nt.  The column half B0 (used by the first and the LAST quadrant
-  // phase of a K-tile) is double-buffered by K-tile parity; B1 (used by the two middle phases) has ONE set that is reloaded for
-  // the next K-tile as soon as the second of them has issued its MFMAs (a third set would not fit 256 registers without spills,
-  // and a spill is a vector-memory operation in the very queue the counted waits rely on).
-  bf16x8 W0a[4], W0b[4], W1[4];
-#define RR_WLD(dst_, HB, KS, kt_)                                                                                   \
-  {                                                                                                                 \
-    const bf16_t* const wb_ = w_tile + (size_t)(kt_) * BK;                                                          \
-    if (!w_noload_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {                                           \
-      if constexpr ((KS) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst_[0 + nt_]) : "v"(woff[HB][nt_]), "s"(wb_) : "memory"); \
-      else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "+v"(dst_[2 + nt_]) : "v"(woff[HB][nt_]), "s"(wb_) : "memory"); \
-    }                                                                                                               \
-  }
-#define RR_BLKW(Q, AF, WS_, IDX)                                                                   \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
-      acc[Q][nt][mt] = mfma16<DT>(WS_[(IDX) + nt], AF[mt], acc[Q][nt][mt]);
 
 #define RR_BLK(Q, AF, BF)                                                                          \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)  \
@@ -1038,12 +1007,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   }
   // ---- first output tile: cold prologue, half-tiles 0..6 in flight (g = 4*tile + {A0:0, B0:1, B1:2, A1:3})
   stage_params(m0, n0);
-  if constexpr (WREG) {                                     // activation half-tiles only: A0(0), A1(0), A0(1)
-    RR_DMA(0, 0) RR_DMA(0, 3) RR_DMA(1, 0)
-  } else {
   RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
   if (nk > 1) { RR_DMA(1, 0) RR_DMA(1, 1) RR_DMA(1, 2) }
-  }
   bool first_tile = true;
   // epilogue timeline (DIAG): ep[0] main loop, [1] next-tile setup + prefetch issue, [2] accumulator arithmetic, then per pass
   // summed: [3] staging writes, [4] prefetch confirm + touch, [5] barrier, [6] residual load issue, [7] residual load wait,
@@ -1057,16 +1022,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // barrier.  Later tiles: every wave confirmed its pieces of the prefetched g0..g4 inside the previous epilogue — before
   // that epilogue's first store, so that the wait never covers a store acknowledgement — and has passed workgroup
   // barriers since: nothing to wait for here.
-  if constexpr (WREG) {
-    // K-tile 0's weight fragments (L2 hits; their latency runs under the accumulator reset below); the empty asm makes both
-    // sets "defined" here, so that the "+v" destinations are not live across the epilogue
-    asm volatile("" : "=v"(W0a[0]), "=v"(W0a[1]), "=v"(W0a[2]), "=v"(W0a[3]), "=v"(W0b[0]), "=v"(W0b[1]), "=v"(W0b[2]), "=v"(W0b[3]),
-                      "=v"(W1[0]), "=v"(W1[1]), "=v"(W1[2]), "=v"(W1[3]));
-    RR_WLD(W0a, 0, 0, 0) RR_WLD(W0a, 0, 1, 0) RR_WLD(W1, 1, 0, 0) RR_WLD(W1, 1, 1, 0)
-  }
   if (first_tile) {
-    if constexpr (WREG) wait_vmcnt<8>();                    // cold queue [params][A0(0) A1(0) A0(1)][8 weight loads]: the half-tiles landed
-    else if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
   }
   if (first_tile) stamp(stamps, 1);
@@ -1077,14 +1034,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   read_a(lds + 0 * HALF, 0, AF0);
-  if constexpr (!WREG) read_b(lds + 1 * HALF, 0, B0K0);
+  read_b(lds + 1 * HALF, 0, B0K0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if constexpr (WREG) {
-    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]));
-    wait_vmcnt<0>();                                        // this tile's K-tile-0 weight fragments (and the parameter pieces) are in
-  } else {
   asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]), "+v"(B0K0[0]), "+v"(B0K0[1]));
-  }
 
   // Diagnostic build (DIAG): per-wave s_memtime marks inside every phase, summed over the loop and written to
   // stamps[block][8 + wave*8 + k]; the marks are read only after the phase's own lgkmcnt(0), so they add no wait.
@@ -1190,93 +1142,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     RR_ACC(8, 5)                                                                                           \
   }
   const bool no_dma = DIAG == 2 && stagger_unit == 61;            // diagnostic: main loop without refills (wrong results)
-  // ---- WREG K-tile.  Vector-memory instructions of a K-tile, in issue order: 1,2 LDS-DMA A1(t+1); 3,4 weights B0K0'; 5,6 B0K1';
-  // 7,8 LDS-DMA A0(t+2); 9,10 B1K0'; 11,12 B1K1' (' = of K-tile t+1, into the other register set).  Counted waits (vmcnt is in
-  // issue order): before a block that first uses a fragment pair of THIS K-tile, everything issued after that pair one K-tile
-  // ago may still be outstanding — p0a 8, p0b 10, p1a 6, p1b 6, X (A0(t+1)) 10, Y (A1(t+1) = 1,2 of this K-tile) 10.  KIND 1 =
-  // the last K-tile but one (no A0(t+2): Y 8), KIND 2 = the last (issues nothing: 6, 4, 2, 0).
-#define RR_WAITW(KIND, a_, b_, c_) { if (!w_nowait) { if constexpr ((KIND) == 0) wait_vmcnt<a_>(); else if constexpr ((KIND) == 1) wait_vmcnt<b_>(); else wait_vmcnt<c_>(); } }
-#define RR_SYNCW(KIND, a_, b_, c_)                       \
-  {                                                      \
-    RR_SBAR();                                           \
-    RR_WAITW(KIND, a_, b_, c_)                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-    __builtin_amdgcn_s_barrier();                        \
-    RR_SBAR();                                           \
-  }
-#define RR_TILEW(KIND, CUR, NXT)                                                                           \
-  {                                                                                                        \
-    const char* sl = lds + (t & 1) * 4 * HALF;               /* this tile's slots: +0 A0, +3 A1 */           \
-    const char* sn = lds + ((t + 1) & 1) * 4 * HALF;                                                       \
-    constexpr bool d1 = (KIND) <= 1, d2 = (KIND) == 0;       /* K-tile t+1 / t+2 exists */                   \
-    /* ---- p0: quadrant (A0, B0) */                                                                        \
-    read_a(sl + 0 * HALF, 1, AF1);                                                                         \
-    RR_SBAR();                                                                                             \
-    RR_WAITW(KIND, 8, 8, 6)                                                                                \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(3)                                                                                             \
-    RR_BLKW(0, AF0, CUR, 0)                                                                                \
-    RR_SBAR();                                                                                             \
-    if constexpr (d1) { RR_DMA(t + 1, 3) RR_WLD(NXT, 0, 0, t + 1) }                                        \
-    RR_SBAR();                                                                                             \
-    RR_WAITW(KIND, 10, 10, 4)                                                                              \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(2)                                                                                             \
-    RR_BLKW(0, AF1, CUR, 2)                                                                                \
-    RR_SBAR();                                                                                             \
-    /* ---- p1: quadrant (A0, B1) */                                                                        \
-    RR_WAITW(KIND, 6, 6, 2)                                                                                \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(1)                                                                                             \
-    RR_BLKW(1, AF0, W1, 0)                                                                                 \
-    RR_SBAR();                                                                                             \
-    read_a(sl + 3 * HALF, 0, AF0);                                                                         \
-    if constexpr (d1) { RR_WLD(NXT, 0, 1, t + 1) }                                                         \
-    RR_SBAR();                                                                                             \
-    RR_WAITW(KIND, 6, 6, 0)                                                                                \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(0)                                                                                             \
-    RR_BLKW(1, AF1, W1, 2)                                                                                 \
-    RR_SYNCW(KIND, 10, 10, 0)                               /* X: A0(t+1) landed */                          \
-    /* ---- p2: quadrant (A1, B1) */                                                                        \
-    read_a(sl + 3 * HALF, 1, AF1);                                                                         \
-    if constexpr (d2) RR_DMA(t + 2, 0)                                                                     \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(3)                                                                                             \
-    RR_BLKW(3, AF0, W1, 0)                                                                                 \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(2)                                                                                             \
-    RR_BLKW(3, AF1, W1, 2)                                                                                 \
-    RR_SBAR();                                                                                             \
-    if constexpr (d1) { RR_WLD(W1, 1, 0, t + 1) }           /* B1 of the next K-tile into the set just used up */ \
-    RR_SBAR();                                                                                             \
-    /* ---- p3: quadrant (A1, B0) */                                                                        \
-    RR_PRIO(1)                                                                                             \
-    RR_BLKW(2, AF0, CUR, 0)                                                                                \
-    RR_SBAR();                                                                                             \
-    if constexpr (d1) { read_a(sn + 0 * HALF, 0, AF0); RR_WLD(W1, 1, 1, t + 1) }                          \
-    RR_SBAR();                                                                                             \
-    RR_PRIO(0)                                                                                             \
-    RR_BLKW(2, AF1, CUR, 2)                                                                                \
-    RR_SYNCW(KIND, 10, 8, 0)                                /* Y: A1(t+1) landed */                          \
-    asm volatile("" : "+v"(AF0[0]), "+v"(AF0[1]), "+v"(AF0[2]), "+v"(AF0[3]));                             \
-  }
-  // diagnostics (wrong results; rr_set_gemm_stagger 60 / 61): 60 = the counted waits in front of the MFMA blocks are skipped (what the
-  // weight loads' LATENCY costs), 61 = the weight loads themselves are skipped too (what their ISSUE costs; the rest is the LDS saving)
-  const bool w_nowait = WREG && (stagger_unit == 60 || stagger_unit == 61);
   int t = 0;
-  if constexpr (WREG) {
-    while (t < nk - 2) { RR_TILEW(0, W0a, W0b) ++t; RR_TILEW(0, W0b, W0a) ++t; }     // nk even (host)
-    RR_TILEW(1, W0a, W0b) ++t;
-    RR_TILEW(2, W0b, W0a) ++t;
-  } else {
   for (; t < nk - 2; ++t) RR_TILE(1)
   for (; t < nk; ++t) RR_TILE(0)
-  }
 #undef RR_TILE
-#undef RR_TILEW
-#undef RR_SYNCW
-#undef RR_WAITW
   if constexpr (DIAG == 2) {
     if (stamps && lane == 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1305,12 +1174,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   if (has_next) {
     tile_origin(chunk0 + li, m0, n0);
     RR_SETUP_SRC(m0, n0)
-    if constexpr (WREG) {
-      RR_DMA(0, 0) RR_DMA(0, 3) RR_DMA(1, 0)
-    } else {
     RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
     if (nk > 1) RR_DMA(1, 0)
-    }
   }
   EP_ADD(1)
 
@@ -1656,7 +1521,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   }
   if (!has_next) break;
   stage_params(m0, n0);                                     // the NEXT tile's (this tile's epilogue has read its own)
-  if constexpr (!WREG) { if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) } }   // slots 5, 6 were under the staging image until now
+  if (nk > 1) { RR_DMA(1, 1) RR_DMA(1, 2) }                 // slots 5, 6 were under the staging image until now
   EP_ADD(10)
   }   // output tiles
   if constexpr (DIAG != 0) {
@@ -1670,8 +1535,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #undef RR_SETUP_SRC
 #undef RR_DMA
 #undef RR_BLK
-#undef RR_BLKW
-#undef RR_WLD
 #undef RR_SBAR
 }
 
@@ -1719,7 +1582,6 @@ inline int desync_arg(int Kd, int epilogue, int nwg, int n_cu) {
   return u > 0 ? 100 + (int)(u > 1000 ? 1000 : u) : 0;
 }
 int g_persistent = 1;                     // rr_set_tuning("persistent_gemm"): 1 = variant 14 for large problems, 0 = variant 12
-std::atomic<int> g_wreg{0};               // rr_set_tuning("gemm_wreg"): weight operand L2 -> VGPR in the persistent ring (gemm_kernel_hp<..., WREG>)
 
 // persistent variant: one workgroup per CU (160 KiB of LDS each), grid = number of CUs rounded down to a multiple of 8
 template <int DT>
@@ -1758,25 +1620,6 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   }
   const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
   if (split && epilogue != EPI_BIAS_RESID_F32) return hipErrorInvalidValue;
-  // WREG (rr_set_tuning "gemm_wreg"): the three production forms with the weight operand straight from L2 into registers
-  if (g_wreg.load() && (Kd / BK) >= 2 && (Kd / BK) % 2 == 0 && !(g_stagger >= 50 && g_stagger <= 56)) {
-#define RR_LAUNCH_W(E, S, F)                                                                                  \
-    {                                                                                                         \
-      auto kern = gemm_kernel_hp<E, DT, S, 0, F, true>;                                                       \
-      static std::atomic<unsigned long long> attr_mask{0};                                                    \
-      {                                                                                                       \
-        hipError_t e = ensure_lds_attr((const void*)kern, lds_bytes, attr_mask);                              \
-        if (e != hipSuccess) return e;                                                                        \
-      }                                                                                                       \
-      hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, \
-                         tiles_n, nwg, stamps, ln, (g_stagger == 60 || g_stagger == 61) ? g_stagger : desync);    \
-      return hipGetLastError();                                                                               \
-    }
-    if (ln.in_stats && !split && epilogue == EPI_BIAS_BF16) RR_LAUNCH_W(EPI_BIAS_BF16, 0, true)
-    if (ln.in_stats && !split && epilogue == EPI_BIAS_GELU_BF16) RR_LAUNCH_W(EPI_BIAS_GELU_BF16, 0, true)
-    if (split == 3) RR_LAUNCH_W(EPI_BIAS_RESID_F32, 3, false)
-#undef RR_LAUNCH_W
-  }
 #define RR_GEMM_SPLIT_CASE(S)                                                                                 \
   case S: {                                                                                                   \
     auto kern = gemm_kernel_hp<EPI_BIAS_RESID_F32, DT, S>;                                                    \
@@ -1962,7 +1805,6 @@ extern "C" int rr_set_gemm_desync(int pct) {
   return 0;
 }
 extern "C" int rr_set_resid_fast(int on) { g_resid_fast.store(on != 0); return 0; }
-extern "C" int rr_set_gemm_wreg(int on) { g_wreg.store(on != 0); return 0; }
 extern "C" int rr_set_gemm_stagger(int unit) {
   if (unit < 0 || unit > 64) return -1;
   g_stagger = unit;

@@ -709,7 +709,6 @@ extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 extern "C" int rr_set_resid_fast(int on);
 extern "C" int rr_set_gemm_ring_min_tiles(int n);
-extern "C" int rr_set_gemm_wreg(int on);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
@@ -1940,7 +1939,6 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "resid_fast")) return rr_set_resid_fast(value);
-  if (!strcmp(key, "gemm_wreg")) return rr_set_gemm_wreg(value);
   if (!strcmp(key, "gemm_ring_min_tiles")) return rr_set_gemm_ring_min_tiles(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
