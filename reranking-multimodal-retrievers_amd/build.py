@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (gemm_bf16.hip ln_apply) now carries an explicit `s_nop 1` behind the loads, so it is safe even with SLP on (verified:
 # 0 wrong elements in 4 launches against 16-48 in each of 4).  The flag stays as the second line of defence: other
 # epilogues add freshly loaded fp32 rows too, and hipcc's hazard recogniser does not know this pair.  Cost 0.7 % of the
-# bench step.  Hand-written 2-wide vector code (attention row sum) only touches VALU-produced values.
+# bench step.  Hand-written 2-wide vector code (the 32-row attention form's row sum) only touches VALU-produced values.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          *os.environ.get("RR_HIPCC_EXTRA", "").split()]          # RR_HIPCC_EXTRA: A/B experiments only
 # per-file extras: the attention softmax has no NaNs by construction; without IEEE-mode canonicalisation its 32-way row

@@ -32,6 +32,15 @@
 
 #include "rr_common.h"
 
+// Row sum of the 64-row form (per tile and sub-block: the lane's 32 probabilities).  1 (default since round 4) = four independent
+// v_add_f32 chains; 0 = round 1-3's single chain of v_pk_add_f32, which hipcc emits as 16 DEPENDENT packed adds with an `s_nop 0`
+// behind each; 2 = a tree of packed adds.  Same box, alternating processes (profiles/r04_s_attn_rowsum_ab.log): 0.887 / 0.875 /
+// 0.875 ms per launch (fp16), 0.855 / 0.842 / 0.842 (bf16).  The scalar form also removes the only packed-f32 arithmetic fed by
+// MFMA results from this file (build.py, the packed-f32 hazard note).
+#ifndef RR_ATTN_ROWSUM
+#define RR_ATTN_ROWSUM 1
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -621,6 +630,25 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
         s[sb][0][r] = __builtin_amdgcn_exp2f(s[sb][0][r]);
         s[sb][1][r] = __builtin_amdgcn_exp2f(s[sb][1][r]);
       }
+#if RR_ATTN_ROWSUM == 1       // four independent scalar chains
+      float c4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c4[j] = s[sb][0][j] + s[sb][1][j];
+#pragma unroll
+      for (int r = 4; r < 16; r += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c4[j] += s[sb][0][r + j]; c4[j] += s[sb][1][r + j]; }
+      l_run[sb] += (c4[0] + c4[1]) + (c4[2] + c4[3]);
+#elif RR_ATTN_ROWSUM == 2     // a tree of packed adds: no add waits for the one before it
+      f32x2v t8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t8[i] = f32x2v{s[sb][0][2 * i], s[sb][0][2 * i + 1]} + f32x2v{s[sb][1][2 * i], s[sb][1][2 * i + 1]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t8[i] += t8[i + 4];
+      t8[0] += t8[2]; t8[1] += t8[3];
+      t8[0] += t8[1];
+      l_run[sb] += t8[0][0] + t8[0][1];
+#else
       f32x2v acc2 = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -628,6 +656,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
         acc2 += f32x2v{s[sb][1][r], s[sb][1][r + 1]};
       }
       l_run[sb] += acc2[0] + acc2[1];
+#endif
     }
     if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[3]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     if (prio) __builtin_amdgcn_s_setprio(2);
