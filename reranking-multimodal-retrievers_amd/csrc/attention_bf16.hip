@@ -42,6 +42,41 @@
 #endif
 
 namespace {
+// The lane's 32 probabilities of one 32-query x 64-key score block, summed in ONE order for every schedule (the 32- and the 64-row
+// fixed-reference forms are bit-for-bit equal, tests/test_gpu_ops.py).
+__device__ __forceinline__ float row_sum32(const f32x16& a, const f32x16& b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2v;
+#if RR_ATTN_ROWSUM == 1       // four independent scalar chains
+  float c4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c4[j] = a[j] + b[j];
+#pragma unroll
+  for (int r = 4; r < 16; r += 4)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c4[j] += a[r + j]; c4[j] += b[r + j]; }
+  return (c4[0] + c4[1]) + (c4[2] + c4[3]);
+#elif RR_ATTN_ROWSUM == 2     // a tree of packed adds: no add waits for the one before it
+  f32x2v t8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t8[i] = f32x2v{a[2 * i], a[2 * i + 1]} + f32x2v{b[2 * i], b[2 * i + 1]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t8[i] += t8[i + 4];
+  t8[0] += t8[2]; t8[1] += t8[3];
+  t8[0] += t8[1];
+  return t8[0][0] + t8[0][1];
+#else                         // rounds 1-3: one chain of packed adds
+  f32x2v acc2 = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    acc2 += f32x2v{a[r], a[r + 1]};
+    acc2 += f32x2v{b[r], b[r + 1]};
+  }
+  return acc2[0] + acc2[1];
+#endif
+}
+}  // namespace
+
+namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 constexpr float LOG2E = 1.4426950408889634f;   // only the DENSE bias is still scaled in the kernel
@@ -372,15 +407,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
     }
-    // row sum over this lane's 32 probabilities, written as a tree so the adds pair up (v_pk_add_f32)
-    typedef __attribute__((ext_vector_type(2))) float f32x2v;
-    f32x2v acc2 = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      acc2 += f32x2v{s0[r], s0[r + 1]};
-      acc2 += f32x2v{s1[r], s1[r + 1]};
-    }
-    l_run += acc2[0] + acc2[1];
+    l_run += row_sum32(s0, s1);       // one summation order for every schedule
 
     if (prio) __builtin_amdgcn_s_setprio(2);
     RR_MARK(2)
@@ -622,7 +649,6 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
       }
       if (got) need_ref = false;       // validity is a property of the keys: both sub-blocks and all lanes agree
     }
-    typedef __attribute__((ext_vector_type(2))) float f32x2v;
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
@@ -630,33 +656,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
         s[sb][0][r] = __builtin_amdgcn_exp2f(s[sb][0][r]);
         s[sb][1][r] = __builtin_amdgcn_exp2f(s[sb][1][r]);
       }
-#if RR_ATTN_ROWSUM == 1       // four independent scalar chains
-      float c4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) c4[j] = s[sb][0][j] + s[sb][1][j];
-#pragma unroll
-      for (int r = 4; r < 16; r += 4)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { c4[j] += s[sb][0][r + j]; c4[j] += s[sb][1][r + j]; }
-      l_run[sb] += (c4[0] + c4[1]) + (c4[2] + c4[3]);
-#elif RR_ATTN_ROWSUM == 2     // a tree of packed adds: no add waits for the one before it
-      f32x2v t8[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t8[i] = f32x2v{s[sb][0][2 * i], s[sb][0][2 * i + 1]} + f32x2v{s[sb][1][2 * i], s[sb][1][2 * i + 1]};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t8[i] += t8[i + 4];
-      t8[0] += t8[2]; t8[1] += t8[3];
-      t8[0] += t8[1];
-      l_run[sb] += t8[0][0] + t8[0][1];
-#else
-      f32x2v acc2 = {0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        acc2 += f32x2v{s[sb][0][r], s[sb][0][r + 1]};
-        acc2 += f32x2v{s[sb][1][r], s[sb][1][r + 1]};
-      }
-      l_run[sb] += acc2[0] + acc2[1];
-#endif
+      l_run[sb] += row_sum32(s[sb][0], s[sb][1]);
     }
     if constexpr (DIAG64) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tmk[3]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     if (prio) __builtin_amdgcn_s_setprio(2);
