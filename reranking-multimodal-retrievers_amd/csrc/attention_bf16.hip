@@ -146,6 +146,19 @@ __device__ __forceinline__ void load_bias_chunk(float* const b_all, int* const f
   __syncthreads();
 }
 
+// The 16 tile flags of the resident chunk as ONE scalar word per wave (bit i: tile i has a bias; bit 16 + i: tile i has no valid
+// key), read once behind load_bias_chunk: the tile loop then tests a bit instead of reading its flag word from LDS and waiting
+// for lgkmcnt(0) at the top of every tile.
+__device__ __forceinline__ uint32_t chunk_flag_bits(const int* const f_all) {
+  const int f = f_all[threadIdx.x & (BIAS_TILES - 1)];
+  const uint32_t any = (uint32_t)__ballot((f & 1) != 0) & 0xFFFFu, none = (uint32_t)__ballot((f & 2) != 0) & 0xFFFFu;
+  return any | (none << 16);
+}
+__device__ __forceinline__ int tile_flags_of(const uint32_t bits, const int t) {
+  const int i = t & (BIAS_TILES - 1);
+  return (int)((bits >> i) & 1u) | (int)(((bits >> (16 + i)) & 1u) << 1);
+}
+
 // ---- output rows through a wave-private LDS slice.  The accumulators hold O^T (lane = query row, registers = head
 // dimensions), so storing them directly is 16 instructions of 8 bytes per lane that each touch 64 different rows.  Staged
 // as rows [query][64 d] in the K/V buffers, which are free after the last tile's barrier, a wave writes its rows as 16
@@ -279,6 +292,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
   const bool prio = (a.tuning & 1) != 0;
   RR_LOAD_TILE(0, 0)
   load_bias_chunk(b_all, f_all, key_bias, b, Tk, 0);
+  uint32_t flag_bits = chunk_flag_bits(f_all);
   RR_WRITE_TILE(0)
   // A wait the compiler can see: the LDS-DMA is counted by hand (asm), so without it hipcc's scoreboard still holds the Q
   // loads as "in flight" on every trip of the loop and puts s_waitcnt vmcnt(6..3) in front of the QK^T MFMAs — which, with
@@ -289,6 +303,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     const int buf = t & 1;
     if (__builtin_expect(t != 0 && (t & (BIAS_TILES - 1)) == 0, 0)) {      // sequences beyond 1024 keys: next bias chunk
       load_bias_chunk(b_all, f_all, key_bias, b, Tk, t / BIAS_TILES);
+      flag_bits = chunk_flag_bits(f_all);
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     RR_MARK(0)
@@ -299,7 +314,7 @@ __device__ __forceinline__ bool attn_block(const int grp, const int qblk, char* 
     // wave-uniform: some key of this tile carries a bias.  DENSE: an additive bias per (query, key) on top of the
     // per-key one (PreFLMR attention fusion, attention_fusion.py:84-102): rows of dense_bias are [Tq][dense_ld],
     // dense_ld a multiple of 64, zero padded; it only exists in the online form.
-    const int tile_flags = __builtin_amdgcn_readfirstlane(f_all[t & (BIAS_TILES - 1)]);   // bit 0: some key has a bias; bit 1: no valid key
+    const int tile_flags = tile_flags_of(flag_bits, t);   // bit 0: some key has a bias; bit 1: no valid key
     const bool masked = DENSE || (tile_flags & 1);
     // Fixed-reference form only: a tile without a single valid key (tail padding) adds exactly 0 to every row sum and to
     // O, so its QK^T, softmax and P.V are skipped (the staging of the next tile and the barrier
@@ -551,6 +566,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
   const bool prio = (a.tuning & 1) != 0;
   load_tile(0, 0);
   load_bias_chunk(b_all, f_all, key_bias, b, Tk, 0);
+  uint32_t flag_bits = chunk_flag_bits(f_all);
   write_tile(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);     // compiler-visible vmcnt(0): see attn_block
   __syncthreads();
@@ -558,6 +574,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     const int buf = t & 1;
     if (__builtin_expect(t != 0 && (t & (BIAS_TILES - 1)) == 0, 0)) {
       load_bias_chunk(b_all, f_all, key_bias, b, Tk, t / BIAS_TILES);
+      flag_bits = chunk_flag_bits(f_all);
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     RR_MK(0)
@@ -565,7 +582,7 @@ __device__ __forceinline__ bool attn_block64(const int grp, const int qblk, char
     const char* kt_ = k_img + buf * TILE_BYTES;
     const char* vt_ = v_img + buf * TILE_BYTES;
     const float* bt_ = b_all + (t & (BIAS_TILES - 1)) * KT;
-    const int tile_flags = __builtin_amdgcn_readfirstlane(f_all[t & (BIAS_TILES - 1)]);   // bit 0: some key has a bias; bit 1: no valid key
+    const int tile_flags = tile_flags_of(flag_bits, t);   // bit 0: some key has a bias; bit 1: no valid key
     const bool masked = (tile_flags & 1) != 0;
     if constexpr (DIAG64) { for (int k_ = 1; k_ < 5; ++k_) tmk[k_] = tmk[0]; }
     if (!(tile_flags & 2)) {     // a tile without a valid key adds exactly 0: skipped (see attn_block)
