@@ -32,6 +32,11 @@
 namespace {
 
 constexpr int BK = 64;
+// K walk direction of an output column (all 16-bit GEMM kernels of this file, so that they keep agreeing to the bit): the
+// columns of every second block of 1 024 (four 256-column slices) accumulate their K-tiles from the last to the first — see the
+// serpentine note in gemm_kernel_hp, whose L2 reuse this serves.  A function of the column alone: a row's arithmetic never
+// depends on M, on the tile shape or on where its tile lies.
+__device__ __forceinline__ int k_walk_reversed(int n0) { return (n0 >> 10) & 1; }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), i.e. waits for every global
 // store / LDS-DMA in flight — between the passes of the staged epilogue that would stall on the previous pass's
@@ -270,9 +275,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = Kd / BK;
+  const int krev = k_walk_reversed(n0);
+  auto kof = [&](int idx) { return (krev ? nk - 1 - idx : idx) * BK; };     // element offset of the idx-th K-tile of the walk
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) stage(s, s * BK);
+    if (s < nk) stage(s, kof(s));
 
   unsigned long long t_wait = 0, t_bar = 0;   // diagnostic accumulators (only when stamps != nullptr)
   for (int kt = 0; kt < nk; ++kt) {
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_s(const bf16_t* __res
     __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt landed; compute(kt-1) is done
     if (stamps) { const unsigned long long tC = __builtin_amdgcn_s_memtime(); t_wait += tB - tA; t_bar += tC - tB; }
     if (kt == 0) stamp(stamps, 1);
-    if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK);
+    if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kof(kt + STAGES - 1));
     const char* a_t = lds + (kt % STAGES) * STAGE_BYTES;
     const char* w_t = a_t + A_BYTES;
 #pragma unroll
@@ -473,11 +480,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
   const bf16_t* const w_tile = W + (size_t)n0 * ldw;
   const uint32_t lds_base = lds_addr(lds);
   const int nk = Kd / BK, H = 4 * nk;
+  const int krev = k_walk_reversed(n0);
   // half-tile (t, J): slot = parity (t&1) * 4 + J; J is a compile-time constant at every call site
 #define RR_DMA(t_, J)                                                                                             \
   {                                                                                                               \
     const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
-    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)(t_) * BK) : (const void*)(w_tile + (size_t)(t_) * BK); \
+    const int tk_ = krev ? nk - 1 - (t_) : (t_);             /* K-tile t of the walk (k_walk_reversed) */                    \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)tk_ * BK) : (const void*)(w_tile + (size_t)tk_ * BK); \
     const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
     glds16_so(sb_, so_[0], dst_);                                                                                 \
     glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
@@ -871,12 +880,22 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // works on at a time are ~4 weight column slices x 8 activation row panels (each W slice is re-used 8 times out of
   // L2 before it is evicted, instead of once per ~3 row panels with a row-major order)
   const int tiles_m = nwg / tiles_n;
+  // Serpentine K walk: the tiles of every second block of four column slices take their K-tiles from the last to the first.
+  // An XCD's round of 32 tiles is 8 row panels x 4 column slices walked in step; the next round has the same 8 panels and the
+  // next 4 slices, and walking it backwards starts on the K slices of the panels that the round before touched LAST — the ones
+  // the 4 MB L2 still holds (about 8 of the 12 at K = 768).  FETCH_SIZE per launch at 409 600 rows: FFN-up 2.83 -> 2.17 GB,
+  // QKV (9 slices: rounds straddle the blocks) 2.47 -> 2.17 GB; FFN-up 1.981 -> 1.927 ms (profiles/r04_x_serpentine.log).  The
+  // direction is a function of the column slice alone, so a row's arithmetic does not depend on where its tile lies (packed ==
+  // padded, bit for bit); shapes of at most four slices (N <= 1024) are untouched.  rr_set_gemm_stagger(59) switches it off.
+  const bool serp = stagger_unit != 59;
+  int krev = 0;
   auto tile_origin = [&](int gidx, int& m0_, int& n0_) {
     const int per_group = GROUP * tiles_n, grp = gidx / per_group, r = gidx - grp * per_group;
     const int rows = min(GROUP, tiles_m - grp * GROUP);
     const int tn = r / rows, tm = grp * GROUP + (r - tn * rows);
     m0_ = tm * BM;
     n0_ = tn * BN;
+    krev = serp ? k_walk_reversed(n0_) : 0;
   };
   tile_origin(chunk0 + li, m0, n0);
 
@@ -907,7 +926,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #define RR_DMA(t_, J)                                                                                             \
   {                                                                                                               \
     const uint32_t dst_ = __builtin_amdgcn_readfirstlane(lds_base + (((t_) & 1) * 4 + (J)) * HALF + wave * 2048); \
-    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)(t_) * BK) : (const void*)(w_tile + (size_t)(t_) * BK); \
+    const int tk_ = krev ? nk - 1 - (t_) : (t_);             /* K-tile t of the walk is K-tile tk_ of the operands */         \
+    const void* sb_ = ((J) == 0 || (J) == 3) ? (const void*)(a_tile + (size_t)tk_ * BK) : (const void*)(w_tile + (size_t)tk_ * BK); \
     const uint32_t* so_ = (J) == 0 ? so_a0 : (J) == 3 ? so_a1 : (J) == 1 ? so_b0 : so_b1;                         \
     glds16_so(sb_, so_[0], dst_);                                                                                 \
     glds16_so(sb_, so_[1], dst_ + 1024);                                                                          \
@@ -1604,7 +1624,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : desync);       \
+                       tiles_n, nwg, stamps, ln, ((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync);       \
   }
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
@@ -1629,7 +1649,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (g_stagger >= 50 && g_stagger <= 56) ? g_stagger : desync);       \
+                       tiles_n, nwg, stamps, ln, ((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync);       \
     return hipGetLastError();                                                                                 \
   }
   switch (split) {

@@ -14,6 +14,8 @@ W = (torch.randn(N, K, generator=g) * 0.02).bfloat16().cuda()
 b = torch.randn(N, generator=g).cuda()
 out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == 2 else torch.bfloat16)
 lib.rr_set_gemm_variant(v)
+if os.environ.get("RR_STAGGER"):            # tile-order / K-walk code of the persistent ring (rr_set_gemm_stagger)
+    assert lib.rr_set_gemm_stagger(int(os.environ["RR_STAGGER"])) == 0
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, epi, out.data_ptr(), st) == 0
