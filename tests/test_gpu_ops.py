@@ -462,6 +462,38 @@ def test_gemm_every_variant_every_epilogue(lib, variant, epi):
         lib.rr_set_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_gemm_rows_do_not_depend_on_where_their_tile_lies(lib, dt):
+    """The K walk of every second block of 1 024 output columns runs backwards (gemm_bf16.hip k_walk_reversed: an XCD's next round
+    of the persistent ring starts on the K slices its L2 still holds).  The direction is a function of the COLUMN alone, in every
+    16-bit GEMM kernel, so a row's values depend neither on M, nor on the kernel the shape heuristic picks, nor on the row's place
+    in the matrix — what packed == bucketed == padded rests on.  Ring kernel (66 000 rows) against the simple kernel on 300 of
+    those rows taken from the middle, FFN-up and QKV widths (12 and 9 column slices), fp32 output: bit for bit; and the reversed
+    columns are as close to the fp64 product as the forward ones."""
+    t16 = torch.float16 if dt else torch.bfloat16
+    assert lib.rr_set_op_dtype(dt) == 0
+    try:
+        for (N, K) in [(3072, 768), (2304, 768), (4096, 1024)]:
+            M, r0, m = 66_000, 31_111, 300
+            g = torch.Generator(device="cpu").manual_seed(N + K + dt)
+            A = torch.randn(M, K, generator=g).to(t16).cuda()
+            W = (torch.randn(N, K, generator=g) * 0.05).to(t16).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            big = torch.empty(M, N, device="cuda")
+            assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, 2, big.data_ptr(), _stream()) == 0
+            sub_in = A[r0:r0 + m].contiguous()
+            small = torch.empty(m, N, device="cuda")
+            assert lib.rr_op_gemm_bf16(sub_in.data_ptr(), W.data_ptr(), b.data_ptr(), m, N, K, 2, small.data_ptr(), _stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(big[r0:r0 + m], small), (N, K, (big[r0:r0 + m] - small).abs().max().item())
+            ref = sub_in.double() @ W.double().t() + b.double()
+            err = (small.double() - ref).abs().view(m, N // 256, 256).amax(dim=(0, 2))
+            fwd = torch.tensor([((c >> 2) & 1) == 0 for c in range(N // 256)], device="cuda")
+            assert err.max().item() < 2e-5 and err[~fwd].max().item() < 1.5 * err[fwd].max().item() + 1e-6, err.tolist()
+    finally:
+        lib.rr_set_op_dtype(0)
+
+
 def test_gemm_production_kernel_equals_simple_kernel_at_bench_shape(lib):
     """The four bert-base GEMM shapes at a bench-sized M (heuristic -> half-tile-ring kernel) against the simple
     128x128 loop on the same operands: same products and fp32 accumulation, only the summation order differs."""
