@@ -23,7 +23,7 @@ for r in range(6):
     for v in vals:
         if key == "gemm_variant":
             assert lib.rr_set_gemm_variant(v) == 0
-        elif key == "gemm_stagger":          # 50..55: tile-order group of 2..64 row panels in the persistent GEMM, 56: row-major, 0: heuristic
+        elif key == "gemm_stagger":          # 50..55: tile-order group of 2..64 row panels in the persistent GEMM, 56: row-major, 59: without the serpentine K walk, 0: heuristic
             assert lib.rr_set_gemm_stagger(v) == 0
         else:
             assert lib.rr_set_tuning(key.encode(), v) == 0

@@ -25,7 +25,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-timeline", action="store_true")
 ap.add_argument("--shapes", default="qkv,attn_out,ffn1,ffn2")
 ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT")
-ap.add_argument("--stagger", type=int, default=0, help="rr_set_gemm_stagger: 50..55 = tile-order group of 2..64 row panels, 56 = row-major")
+ap.add_argument("--stagger", type=int, default=0, help="rr_set_gemm_stagger: 50..55 = tile-order group of 2..64 row panels, 56 = row-major, 59 = no serpentine K walk")
 a = ap.parse_args()
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
