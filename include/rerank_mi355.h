@@ -454,7 +454,8 @@ int rr_set_gemm_variant(int variant);
  * plus switches that select between bit-identical kernels or only move time: "resid_fast" (default 1: plain fp32 residual GEMMs
  * on the split forms' epilogue), "resid_touch" (0: L2 touch of the next residual pass), "gemm_desync" (0: start skew of the XCDs,
  * percent of a tile period), "persistent_gemm" (1), "gemm_ring_min_tiles" (128: smallest problem, in 256 x 256 tiles, on the
- * persistent ring),
+ * persistent ring), "m_alternate" (1: consecutive large launches of the layer chain walk the rows in opposite directions, so that
+ * a consumer starts on the rows its producer wrote last; results bit-identical either way),
  * "attn_prio" (1).  Not thread-safe against running forwards; never needed on the product path. */
 int rr_set_tuning(const char* key, int value);
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */

@@ -203,16 +203,19 @@ struct AttnArgs {
   unsigned long long* stamps; int tuning;
   int* flags; int nblk;      // fixed-reference schedule: one word per workgroup of the grid, 1 = recompute online
   unsigned long long* redo_stats;   // diagnostic (rr_set_attn_redo_stats): [0] += flagged workgroups, [1] += workgroups looked at; nullptr in production
+  int rev;                          // 1: the grid walks the (sequence, head) groups from the last to the first (rr_m_direction_next)
 };
 
 // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
 // read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
 // into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
 // bid must be wave-uniform; nqb = query blocks per (sequence, head).  False for the padding ids of the last 8-group.
-__device__ __forceinline__ bool block_map(const int bid, const int nqb, const int groups, int& grp, int& qblk) {
+__device__ __forceinline__ bool block_map(const int bid, const int nqb, const int groups, int& grp, int& qblk, const int rev = 0) {
   const int xcd = bid & 7, local = bid >> 3;
-  grp = (local / nqb) * 8 + xcd;
-  qblk = local - (local / nqb) * nqb;
+  int g8 = local / nqb;                                     // 8-group of (sequence, head) pairs, in dispatch order
+  qblk = local - g8 * nqb;
+  if (rev) g8 = (groups + 7) / 8 - 1 - g8;                  // same workgroups, same XCDs, the groups taken from the end
+  grp = g8 * 8 + xcd;
   return grp < groups;
 }
 
@@ -759,7 +762,7 @@ template <int DT, bool DIAG64 = false>
 __global__ __launch_bounds__(256, 2) void attn_fixed64_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[ATTN_LDS_BYTES];
   int grp, qblk;
-  const bool redo = block_map(blockIdx.x, (a.Tq + 255) >> 8, a.groups, grp, qblk) && attn_block64<DT, DIAG64>(grp, qblk, lds, a);
+  const bool redo = block_map(blockIdx.x, (a.Tq + 255) >> 8, a.groups, grp, qblk, a.rev) && attn_block64<DT, DIAG64>(grp, qblk, lds, a);
   if (threadIdx.x == 0) a.flags[blockIdx.x] = redo ? 1 : 0;
 }
 
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void attn_redo_kernel(const AttnArgs a) {
   }
   for (int j = 0; j < n; ++j) {     // workgroups are independent: the order inside the list does not matter
     int grp, qblk;
-    if (!block_map(__builtin_amdgcn_readfirstlane(list[j]), (a.Tq + 128 * SPLIT - 1) / (128 * SPLIT), a.groups, grp, qblk)) continue;
+    if (!block_map(__builtin_amdgcn_readfirstlane(list[j]), (a.Tq + 128 * SPLIT - 1) / (128 * SPLIT), a.groups, grp, qblk, a.rev)) continue;
 #pragma unroll
     for (int part = 0; part < SPLIT; ++part) {
       if ((qblk * SPLIT + part) * 128 < a.Tq) attn_block<DT, false, false, false>(grp, qblk * SPLIT + part, lds, a);
@@ -945,6 +948,7 @@ hipError_t rr_launch_attention(const bf16_t* q, int q_stride, int q_batch_div, i
     if (rows64 && (!diag || fixed_host == 2)) {     // (stamps + attn_fixed_ref 2: the 64-row form's own timeline)
       const long nblk64 = ((groups + 7) / 8) * 8 * ((Tq + 255) / 256);
       a.nblk = (int)nblk64;
+      a.rev = nblk64 >= 2048 ? rr_m_direction_next() : 0;      // large launches take part in the alternation of walking directions
       hipError_t e = attn_flags(nblk64, st, &a.flags);
       if (e != hipSuccess) return e;
       const dim3 grid64((unsigned)nblk64), rgrid((unsigned)((nblk64 + REDO_SPAN - 1) / REDO_SPAN));

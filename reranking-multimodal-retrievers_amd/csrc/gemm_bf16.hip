@@ -846,6 +846,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // model reproduces FETCH_SIZE per kernel to 3-8 % (DESIGN.md "Round 3", profiles/r03_q_*).  8 row panels x 4 column
   // slices is the cheapest rectangle of 32; the step time is the same to 0.2 % for groups of 1 / 4 / 8
   // (profiles/r03_q_tile_order_ab.txt).
+  const bool mrev = stagger_unit >= 1000;                   // this launch walks its tile lists from the end (rr_m_direction_next)
+  if (mrev) stagger_unit -= 1000;
   const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50))      // A/B: 2..64
                     : (stagger_unit == 56 || Kd > 1024) ? 1 : 8;
   // De-synchronise the XCDs (rr_set_tuning "gemm_desync"; stagger_unit = 100 + u).  All workgroups of a persistent launch start
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     n0_ = tn * BN;
     krev = serp ? k_walk_reversed(n0_) : 0;
   };
-  tile_origin(chunk0 + li, m0, n0);
+  tile_origin(chunk0 + (mrev ? chunk_n - 1 - li : li), m0, n0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1192,7 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   li += gstep;
   const bool has_next = li < chunk_n;
   if (has_next) {
-    tile_origin(chunk0 + li, m0, n0);
+    tile_origin(chunk0 + (mrev ? chunk_n - 1 - li : li), m0, n0);
     RR_SETUP_SRC(m0, n0)
     RR_DMA(0, 0) RR_DMA(0, 1) RR_DMA(0, 2) RR_DMA(0, 3)
     if (nk > 1) RR_DMA(1, 0)
@@ -1615,6 +1617,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
   dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
   unsigned long long* stamps = g_stamps;
   const int desync = desync_arg(Kd, epilogue, nwg, n_cu);
+  const int mrev = nwg >= 2 * n_cu ? rr_m_direction_next() : 0;      // large launches only take part in the alternation
 #define RR_GEMM_CASE_F(E, F)                                                                                  \
   {                                                                                                           \
     auto kern = gemm_kernel_hp<E, DT, 0, 0, F>;                                                               \
@@ -1624,7 +1627,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, ((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync);       \
+                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
   }
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
@@ -1649,7 +1652,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, ((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync);       \
+                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
     return hipGetLastError();                                                                                 \
   }
   switch (split) {
@@ -1836,6 +1839,9 @@ extern "C" int rr_set_gemm_stamps(void* device_buf) {
   return 0;
 }
 
+std::atomic<int> g_m_alternate{1}, g_m_counter{0};       // rr_set_tuning("m_alternate"), default on: see rr_m_direction_next (rr_common.h)
+extern "C" int rr_set_m_alternate(int on) { g_m_alternate.store(on != 0); g_m_counter.store(0); return 0; }
+int rr_m_direction_next() { return g_m_alternate.load() ? (g_m_counter.fetch_add(1) & 1) : 0; }
 std::atomic<int> g_resid_split{1};       // rr_set_tuning("resid_split")
 // Smallest problem (in 256 x 256 tiles) that runs the persistent ring; below it the 128 x 128 two-stage kernel.  Measured per
 // shape at the strong-scaling shard sizes of one K = 100 query (profiles/r04_e_midsize_variants.log, M = 6 656 / 12 800 / 25 600):

@@ -711,6 +711,7 @@ extern "C" int rr_set_resid_fast(int on);
 extern "C" int rr_set_gemm_ring_min_tiles(int n);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
+extern "C" int rr_set_m_alternate(int on);
 int g_ln_lite = 1;   // tuning (rr_set_tuning "ln_lite"): 1 = recompute the residual from LN statistics, 0 = materialise fp32
 
 // Where a layer's residual comes from: either materialised fp32 rows (after an embedding LayerNorm), or the previous
@@ -1941,6 +1942,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_fast")) return rr_set_resid_fast(value);
   if (!strcmp(key, "gemm_ring_min_tiles")) return rr_set_gemm_ring_min_tiles(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
+  if (!strcmp(key, "m_alternate")) return rr_set_m_alternate(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);
   if (!strcmp(key, "attn_fixed_ref")) return rr_set_attn_fixed_ref(value);
   return RR_ERR_BAD_ARG;
