@@ -209,14 +209,19 @@ struct AttnArgs {
 // XCD-aware block map: workgroups go to the 8 XCDs round-robin by id, and all query blocks of one (sequence, head)
 // read the same K/V.  Keep them on ONE XCD (ids congruent mod 8, consecutive in dispatch order) so K/V are fetched
 // into that L2 once instead of once per query block (measured 5.6 GB beyond L2 per launch vs 2.5 GB algorithmic).
-// bid must be wave-uniform; nqb = query blocks per (sequence, head).  False for the padding ids of the last 8-group.
+// XCD x takes the x-th CONTIGUOUS eighth of the (sequence, head) groups — the rows the x-th XCD of the persistent GEMM before and
+// behind this launch wrote / will read (its tile lists are chunked the same way) — from its first to its last group, or from the
+// last to the first (rev: rr_m_direction_next), so that with alternating directions each XCD starts on the rows that were
+// written last.  Which XCD computes a group changes nothing in its values.  bid must be wave-uniform; nqb = query blocks per
+// (sequence, head).  False for the padding ids (the grid holds ceil(groups / 8) slots per XCD).
 __device__ __forceinline__ bool block_map(const int bid, const int nqb, const int groups, int& grp, int& qblk, const int rev = 0) {
   const int xcd = bid & 7, local = bid >> 3;
-  int g8 = local / nqb;                                     // 8-group of (sequence, head) pairs, in dispatch order
-  qblk = local - g8 * nqb;
-  if (rev) g8 = (groups + 7) / 8 - 1 - g8;                  // same workgroups, same XCDs, the groups taken from the end
-  grp = g8 * 8 + xcd;
-  return grp < groups;
+  const int j = local / nqb;                                // this XCD's j-th group, in dispatch order
+  qblk = local - j * nqb;
+  const int q8 = groups >> 3, r8 = groups & 7;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  grp = chunk0 + (rev ? chunk_n - 1 - j : j);
+  return j < chunk_n;
 }
 
 // One workgroup's share: the 128 query rows [128 qblk, 128 qblk + 128) of (pair, head) = grp.
