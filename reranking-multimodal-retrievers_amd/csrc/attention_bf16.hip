@@ -45,7 +45,9 @@ namespace {
 // The lane's 32 probabilities of one 32-query x 64-key score block, summed in ONE order for every schedule (the 32- and the 64-row
 // fixed-reference forms are bit-for-bit equal, tests/test_gpu_ops.py).
 __device__ __forceinline__ float row_sum32(const f32x16& a, const f32x16& b) {
+#if RR_ATTN_ROWSUM != 1
   typedef __attribute__((ext_vector_type(2))) float f32x2v;
+#endif
 #if RR_ATTN_ROWSUM == 1       // four independent scalar chains
   float c4[4];
 #pragma unroll
