@@ -303,7 +303,8 @@ def main():
 
     def step():
         if distributed:      # also with one rank: the same slice -> all-gather -> head path the N-GPU runs take
-            return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None, want_scores=True)
+            # status words of the exchange are looked at when the next step begins / after the timed loop: no host read per step
+            return sharded_forward(eng, ids, am, tt, Bq, K, cls, pat, None, want_scores=True, defer_status=True)
         if args.bucketed:
             return eng.forward_ids_bucketed(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
         if args.packed:        # the pair lengths are host data in the real pipeline (the tokenizer produced them)
@@ -313,6 +314,8 @@ def main():
 
     def fence():
         if distributed:
+            from rmr_amd.sharding import check_deferred_status
+            check_deferred_status()                    # raises on every rank if any rank's encoder failed in an earlier step
             dist.barrier()
         torch.cuda.synchronize(dev)
 

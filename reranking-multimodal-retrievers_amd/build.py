@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librerank_mi355.so")
 SOURCES = ["rr_api.hip", "gemm_bf16.hip", "gemm_fp8.hip", "attention_bf16.hip", "elementwise.hip", "head.hip", "pair_tokenizer.cpp"]
 HEADERS = [os.path.join(CSRC, "rr_common.h"), os.path.join(os.path.dirname(HERE), "include", "rerank_mi355.h"),
+           os.path.join(os.path.dirname(HERE), "include", "rerank_mi355_diag.h"),
            os.path.join(CSRC, "unicode_tables.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: no compiler-formed v_pk_*_f32.  Root cause of the corruption it was added for (round 2, ISA and

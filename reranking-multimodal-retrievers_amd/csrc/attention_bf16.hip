@@ -878,6 +878,7 @@ static int g_attn_prio_host = 1, g_attn_fixed_host = ATTN_FIXED_DEFAULT;
 constexpr long ATTN_FIXED_MIN_BLOCKS = 1024;   // below this the launch, not the softmax, is what costs
 extern "C" int rr_set_attn_prio(int on) { g_attn_prio_host = on != 0; return 0; }
 extern "C" int rr_set_attn_fixed_ref(int v) { g_attn_fixed_host = (v < 0 || v > 3) ? ATTN_FIXED_DEFAULT : v; return 0; }   // out of range: back to the default
+extern "C" int rr_get_attn_fixed_ref(void) { return g_attn_fixed_host; }
 extern "C" int rr_set_attn_stamps(void* device_buf) {   // diagnostic: 4 waves x 8 uint64 per workgroup, or NULL
   g_attn_stamps = (unsigned long long*)device_buf;
   return 0;

@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // 65 504).  max |x| <= sqrt(sum x^2) = sqrt(M2 + n mean^2), so a row whose sum of squares stays below RANGE_SS cannot hold
 // an element above 3e4; a row that reaches it (or is not finite) raises *range_flag — the statistics are taken from the
 // fp32 values before the 16-bit rounding, so the test still works when the rounding has already overflowed.
-constexpr float RANGE_SS = 9.0e8f;
+// The limit is the caller's: RR_RANGE_SS_FP16 for fp16 operand rows; +inf for bf16 rows, whose exponent range is
+// fp32's — there only a NON-FINITE row raises the flag (`!(x < inf)` holds for inf and NaN alone).
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, int nparts, int cols, float eps,
-                                                          int rows, float2* __restrict__ stats, int* __restrict__ range_flag) {
+                                                          int rows, float2* __restrict__ stats, int* __restrict__ range_flag,
+                                                          float range_ss) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const float2* p = part + (size_t)row * nparts;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
     n = nt;
   }
   stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / n + eps));
-  if (range_flag && !(m2 + n * mean * mean < RANGE_SS)) atomicOr(range_flag, 1);      // (NaN fails the comparison too)
+  if (range_flag && !(m2 + n * mean * mean < range_ss)) atomicOr(range_flag, 1);      // (NaN fails the comparison too)
 }
 
 // ---- LayerNorm whose output is the e4m3 operand of an fp8 GEMM (BASELINE configs[4]): y = LN(x) in fp32, one scale per
@@ -534,10 +536,10 @@ hipError_t rr_launch_split_residual_value(const bf16_t* hi, const bf16_t* lo, co
 }
 
 hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st,
-                                 int* range_flag) {
+                                 int* range_flag, float range_ss) {
   if (rows <= 0 || cols <= 0 || nparts != (cols + 127) / 128 || !part || !stats) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float2*)part, nparts, cols, eps,
-                     rows, (float2*)stats, range_flag);
+                     rows, (float2*)stats, range_flag, range_ss);
   return hipGetLastError();
 }
 

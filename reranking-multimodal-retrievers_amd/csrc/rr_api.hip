@@ -4,7 +4,7 @@
 // The sequence restates /root/reference/src/models/rerank/rerank_model.py:523-591
 // (FullContextRerankModel.forward) -> :333-479 (RerankModel.query) -> utils.py:85-108 (CrossEncoder)
 // -> utils.py:228-254 (head); everything runs on the device, there is no CPU fallback.
-#include "../../include/rerank_mi355.h"
+#include "../../include/rerank_mi355_diag.h"   // product ABI (rerank_mi355.h) + the diagnostic entry points
 #include "rr_common.h"
 
 #include <cmath>
@@ -147,8 +147,12 @@ struct ProfEvent {
 }  // namespace
 
 // Options of a handle that change which arithmetic a forward runs (include/rerank_mi355.h, rr_set_option)
-enum RrOption { RR_OPT_LN_LITE = 0, RR_OPT_LN_FOLD, RR_OPT_CE_CLS_ONLY, RR_OPT_FP8_FFN_DOWN, RR_OPT_RESID_SPLIT, RR_OPT_ATTN_FIXED_REF, RR_OPT_COUNT };
-static const char* const kOptionKeys[RR_OPT_COUNT] = {"ln_lite", "ln_fold", "ce_cls_only", "fp8_ffn_down", "resid_split", "attn_fixed_ref"};
+enum RrOption { RR_OPT_LN_LITE = 0, RR_OPT_LN_FOLD, RR_OPT_CE_CLS_ONLY, RR_OPT_FP8_FFN_DOWN, RR_OPT_RESID_SPLIT, RR_OPT_ATTN_FIXED_REF,
+                RR_OPT_FP8_FIRST_LAYER, RR_OPT_FP8_QKV, RR_OPT_COUNT };
+static const char* const kOptionKeys[RR_OPT_COUNT] = {"ln_lite", "ln_fold", "ce_cls_only", "fp8_ffn_down", "resid_split", "attn_fixed_ref",
+                                                      "fp8_first_layer", "fp8_qkv"};
+// largest value of an option (the smallest is always -1 = "not set")
+static int option_max(int which) { return which == RR_OPT_ATTN_FIXED_REF ? 3 : which == RR_OPT_FP8_FIRST_LAYER ? 4096 : 1; }
 
 struct rr_model {
   rr_config cfg;
@@ -188,7 +192,7 @@ struct rr_model {
   int padded_S = 0;                    // rr_set_padded_seq_len: the padded text length whose cross-encoder positions a shorter forward keeps (0 = off)
   // Per-handle numerics options (rr_set_option): -1 = follow the process-wide diagnostic switch of the same name (rr_set_tuning),
   // 0 / 1 / ... = pinned for this handle.  Two handles of one process may differ (no global state on the path).
-  int opt[RR_OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
+  int opt[RR_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
   bool pinned_blocks = false;          // a stream capture was seen on this handle: outgrown blocks are retired, not freed
   std::vector<void*> retired;          // outgrown workspace / bias blocks that a captured graph may still reference; freed by rr_destroy
 
@@ -743,8 +747,13 @@ struct ResidSrc {
 
 int g_ce_cls_only = 1;                   // tuning (rr_set_tuning "ce_cls_only"): 1 = the cross-encoder's last layer computes the CLS rows only
 int g_fp8_ffn_down = 0;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too (opt-in: ADVICE r3, DESIGN.md "fp8")
+int g_fp8_first_layer = 0;               // tuning / option "fp8_first_layer": text-encoder layers below this index keep 16-bit operands in the fp8 configuration
+int g_fp8_qkv = 1;                       // tuning / option "fp8_qkv": 0 = only the FFN of an fp8 layer takes e4m3 operands, its QKV projection stays 16-bit
 constexpr float FP8_GELU_MUL = 8.0f;     // static scale of the e4m3 GELU output feeding it
 int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
+
+// limit of the range guard (ln_finalize_kernel): fp16 operand rows are refused from 3e4 on, bf16 rows only when not finite
+inline float range_ss_of(const rr_model* m) { return m->dt == 1 ? RR_RANGE_SS_FP16 : __builtin_inff(); }
 
 extern "C" int rr_get_resid_split(void);
 // effective value of a handle option: the handle's own setting, else the process-wide switch
@@ -756,6 +765,8 @@ inline int opt_of(const rr_model* m, int which) {
     case RR_OPT_CE_CLS_ONLY: return g_ce_cls_only;
     case RR_OPT_FP8_FFN_DOWN: return g_fp8_ffn_down;
     case RR_OPT_RESID_SPLIT: return rr_get_resid_split();
+    case RR_OPT_FP8_FIRST_LAYER: return g_fp8_first_layer;
+    case RR_OPT_FP8_QKV: return g_fp8_qkv;
     default: return -1;      // RR_OPT_ATTN_FIXED_REF: -1 lets the attention launcher take its own process-wide mode
   }
 }
@@ -792,7 +803,11 @@ struct SegView {           // what run_layer needs: rows per pair and the first 
 
 int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq, int Hd, int heads, int I, float eps,
               const float* key_bias, Work& w, ResidSrc& rs, int& in_kind, bool want_h32, bool want_f32,
-              const float* dense_bias = nullptr, int dense_ld = 0, const std::vector<SegView>* segs = nullptr) {
+              const float* dense_bias = nullptr, int dense_ld = 0, const std::vector<SegView>* segs = nullptr, int fp8_layer = -1,
+              bool next_fp8 = false) {
+  // fp8_layer: -1 = every layer that holds e4m3 weights runs the fp8 configuration (cfg.fp8), 0 / 1 = the caller's per-layer
+  // choice ("fp8_first_layer"); next_fp8: the NEXT layer of the stack runs the fp8 configuration, whose residual epilogues read
+  // fp32 rows — a folded layer in front of it leaves its output rows as fp32 (w.pre2) instead of the (hi, lo) pair.
   int rows = batch * Tseq;
   if (segs) {
     if (dense_bias) return fail(m, RR_ERR_UNSUPPORTED, "internal: dense attention bias with packed segments");
@@ -803,7 +818,8 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
   const int nparts = (Hd + 127) / 128;
   const bool ln_lite = opt_of(m, RR_OPT_LN_LITE) != 0;
   const int attn_mode = opt_of(m, RR_OPT_ATTN_FIXED_REF);
-  const bool fp8 = m->cfg.fp8 && ln_lite && L.w1_8 && (Hd % 128 == 0);
+  const bool fp8 = m->cfg.fp8 && fp8_layer != 0 && ln_lite && L.w1_8 && (Hd % 128 == 0);
+  const bool fp8_qkv_next = opt_of(m, RR_OPT_FP8_QKV) != 0;      // the e4m3 rows this layer leaves feed the next layer's QKV projection
   const bool fold = !fp8 && opt_of(m, RR_OPT_LN_FOLD) && ln_lite && L.w1_f && (Hd % 8 == 0);
   if (in_kind == OP_RAW_FOLDED) {
     if (!L.wqkv_f) return fail(m, RR_ERR_BAD_ARG, "internal: folded operand into a layer without folded QKV weights");
@@ -872,9 +888,9 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
       RR_GEMM_FP8(m, st, w.h16, Hd, L.w1_8, L.b1, w.rowscale, L.s1, w.mid, I, rows, I, Hd, 1);
       RR_GEMM_LN(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, 4.0);
     }
-    if (want_h32) {
-      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_f32 ? 10.0 : 6.0) * rows * Hd,
-             rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_f32 ? w.h32 : nullptr, w.h16, w.stats_b,
+    if (want_h32 || !fp8_qkv_next || !next_fp8) {      // 16-bit normalised rows: end of the stack, "fp8_qkv" 0, or a 16-bit layer follows
+      RR_RUN(m, st, RR_K_LAYERNORM, 0.0, (want_h32 && want_f32 ? 10.0 : 6.0) * rows * Hd,
+             rr_launch_layernorm_stats(w.pre2, L.ln2g, L.ln2b, eps, rows, Hd, want_h32 && want_f32 ? w.h32 : nullptr, w.h16, w.stats_b,
                                        m->dt, st));
       in_kind = OP_NORMALISED;
     } else {
@@ -903,7 +919,7 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     if (split) f1.lo_out = lo16;
     RR_GEMM_LN_PREP(m, st, w.ctx, Hd, L.wo, L.bo, rs, w.pre, Hd, rows, Hd, Hd, f1);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
-           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st, m->range_flag));
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_a, st, m->range_flag, range_ss_of(m)));
     GemmFold fi;
     fi.in_stats = w.stats_a;
     fi.csum = L.c1_f;
@@ -912,11 +928,11 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     if (split) { r1.x = nullptr; r1.hi = w.h16; r1.lo = lo16; }
     GemmFold f2 = fo;                      // FFN-down: residual = r1, output -> (h16, lo16) in place, or fp32 w.pre2
     f2.r_hi = r1.hi; f2.r_lo = r1.lo; f2.ld16 = Hd;
-    const bool split_out = split && !want_h32;
+    const bool split_out = split && !want_h32 && !next_fp8;
     if (split_out) f2.lo_out = lo16;
     RR_GEMM_LN_PREP(m, st, w.mid, I, L.w2, L.b2, r1, w.pre2, Hd, rows, Hd, I, f2);
     RR_RUN(m, st, RR_K_LAYERNORM, 0.0, 8.0 * rows * (nparts + 1),
-           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st, m->range_flag));
+           rr_launch_ln_finalize(w.lnpart, nparts, Hd, eps, rows, w.stats_b, st, m->range_flag, range_ss_of(m)));
     rs = ResidSrc{w.pre2, w.stats_b, L.ln2g, L.ln2b};
     if (split_out) { rs.x = nullptr; rs.hi = w.h16; rs.lo = lo16; }
     in_kind = OP_RAW_FOLDED;
@@ -1428,10 +1444,15 @@ static int rr_head_impl(rr_handle h, const float* logits, const float* logits2, 
 // Sticky range error (include/rerank_mi355.h, rr_activation_range_flag): look at what the PREVIOUS forwards left in the pinned
 // word (no synchronisation: a copy still in flight simply reports one call later), refuse to go on once it is raised.
 static int range_guard_enter(rr_model* m) {
-  if (m->range_flag_host && *(volatile int*)m->range_flag_host)
-    return fail(m, RR_ERR_RANGE, "an earlier forward's pre-LayerNorm rows left the fp16 range (flag %d): its logits are unreliable; "
-                                 "clear with rr_activation_range_flag(reset = 1) and use compute_dtype = bf16 for this checkpoint",
+  if (m->range_flag_host && *(volatile int*)m->range_flag_host) {
+    if (m->dt == 1)
+      return fail(m, RR_ERR_RANGE, "an earlier forward's pre-LayerNorm rows left the fp16 range (flag %d): its logits are unreliable; "
+                                   "clear with rr_activation_range_flag(reset = 1) and use compute_dtype = bf16 for this checkpoint",
+                  *(volatile int*)m->range_flag_host);
+    return fail(m, RR_ERR_RANGE, "an earlier forward's pre-LayerNorm rows were not finite (flag %d; bf16 rows have fp32's range, so "
+                                 "this is inf / NaN in the inputs or weights): clear with rr_activation_range_flag(reset = 1)",
                 *(volatile int*)m->range_flag_host);
+  }
   return RR_OK;
 }
 static int range_guard_exit(rr_model* m, hipStream_t st) {
@@ -1552,9 +1573,11 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
     int folded = OP_NORMALISED;
+    const int fp8_from = c.fp8 ? opt_of(m, RR_OPT_FP8_FIRST_LAYER) : 0;      // layers below it keep 16-bit operands ("fp8_first_layer")
     for (int l = 0; l < c.layers; ++l)                    // the last layer's normalised rows feed the 768 -> 128 projection
       RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs, folded,
-                       l == c.layers - 1, m->debug, nullptr, 0, tv));
+                       l == c.layers - 1, m->debug, nullptr, 0, tv, c.fp8 ? (l >= fp8_from ? 1 : 0) : -1,
+                       c.fp8 && l + 1 < c.layers && l + 1 >= fp8_from));
   }
   if (m->debug) {
     const size_t el = (size_t)R * Hd;
@@ -1912,21 +1935,29 @@ static int option_index(const char* key) {
     if (!strcmp(key, kOptionKeys[i])) return i;
   return -1;
 }
+extern "C" int rr_get_attn_fixed_ref(void);
 int rr_set_option(rr_handle h, const char* key, int value) {
   if (!h) return RR_ERR_BAD_ARG;
-  const int i = option_index(key);
-  if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_set_option: unknown key '%s'", key ? key : "(null)");
-  if (value < -1 || (i != RR_OPT_ATTN_FIXED_REF && value > 1) || value > 3)
-    return fail(h, RR_ERR_BAD_ARG, "rr_set_option: %s = %d out of range", key, value);
-  h->opt[i] = value;
-  return RR_OK;
+  return guarded(h, [&]() -> int {
+    const int i = option_index(key);
+    if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_set_option: unknown key '%s'", key ? key : "(null)");
+    if (value < -1 || value > option_max(i))
+      return fail(h, RR_ERR_BAD_ARG, "rr_set_option: %s = %d out of range", key, value);
+    h->opt[i] = value;
+    return RR_OK;
+  });
 }
 int rr_get_option(rr_handle h, const char* key, int* value_out) {
   if (!h || !value_out) return RR_ERR_BAD_ARG;
-  const int i = option_index(key);
-  if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_get_option: unknown key '%s'", key ? key : "(null)");
-  *value_out = opt_of(h, i);
-  return RR_OK;
+  return guarded(h, [&]() -> int {
+    const int i = option_index(key);
+    if (i < 0) return fail(h, RR_ERR_BAD_ARG, "rr_get_option: unknown key '%s'", key ? key : "(null)");
+    // the EFFECTIVE value: opt_of keeps -1 for an unpinned "attn_fixed_ref" (the launcher then takes its process-wide mode);
+    // a reader is shown that mode
+    const int v = opt_of(h, i);
+    *value_out = (i == RR_OPT_ATTN_FIXED_REF && v < 0) ? rr_get_attn_fixed_ref() : v;
+    return RR_OK;
+  });
 }
 
 // ---- stand-alone operators ---------------------------------------------------------------------
@@ -1935,6 +1966,8 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "fp8_ffn_down")) { g_fp8_ffn_down = value != 0; return RR_OK; }
+  if (!strcmp(key, "fp8_first_layer")) { g_fp8_first_layer = value < 0 ? 0 : value; return RR_OK; }
+  if (!strcmp(key, "fp8_qkv")) { g_fp8_qkv = value != 0; return RR_OK; }
   if (!strcmp(key, "ce_cls_only")) { g_ce_cls_only = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
   if (!strcmp(key, "resid_touch")) return rr_set_resid_touch(value);

@@ -300,8 +300,9 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
 // box: 87.44 / 87.61 / 87.46 ms off, 87.22 / 87.50 / 87.28 on).  A process-wide launch counter decides, nothing else depends on it;
 // launches of fewer than two tiles per CU / 2 048 attention blocks do not take part.  0 = ascending.
 int rr_m_direction_next();
+constexpr float RR_RANGE_SS_FP16 = 9.0e8f;      // row sum of squares below which no element can exceed 3e4 (fp16 operand rows)
 hipError_t rr_launch_ln_finalize(const float* part, int nparts, int cols, float eps, int rows, float* stats, hipStream_t st,
-                                 int* range_flag = nullptr);
+                                 int* range_flag = nullptr, float range_ss = RR_RANGE_SS_FP16);
 
 // fp8 (csrc/gemm_fp8.hip, elementwise.hip)
 hipError_t rr_launch_gemm_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* bias, float scale,

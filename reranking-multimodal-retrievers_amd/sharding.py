@@ -6,11 +6,20 @@ ROCm; gloo in the CPU tests) and the scoring head + top-K run redundantly on eve
 The reference has no such exchange (DDP shards queries, every rank writes its own JSON —
 /root/reference/src/executors/Reranker_base_executor.py:1118-1121); this is the new collective of SURVEY §8e.
 
-Buffers: the send slice, the gathered block and (ragged case only) the compacted logits are allocated once per
+Buffers: the send slice, the gathered block and the compacted logits (+ status words) are allocated once per
 (device, world size, slice length, heads) and reused by every later batch of that shape — no allocation and no
 `torch.cat` in the steady state.  Both heads of the 2H_BCE variant travel in the same collective.  The collective is
 enqueued by `torch.distributed` behind the work stream's kernels (ProcessGroupNCCL waits on the current stream's
 event and the current stream waits on the collective), so the encoder of the next batch may already be enqueued.
+
+Errors are COLLECTIVE: an exception inside one rank's encoder — e.g. the sticky RR_ERR_RANGE of a handle whose
+pair slice left the fp16 range, which depends on that rank's own pairs — must not leave the other ranks waiting in the
+all-gather.  Every rank's block therefore ends in one status word (0 ok / 1 range error / 2 any other error); a failing rank
+still takes part in the exchange (zero logits, its status word set) and every rank raises after it: the failing rank its own
+exception, the others `ShardPeerError` (an OverflowError when the peer's was one) naming the ranks.  Reading the status words
+is one host read of `world` floats per batch; a loop that must not synchronise per batch passes `defer_status=True`: the words
+are copied to pinned memory behind the collective and looked at when the NEXT batch begins (before any collective of that
+batch, so still on every rank together) or in `check_deferred_status()`, which such a loop calls before it uses its results.
 """
 from __future__ import annotations
 
@@ -27,24 +36,40 @@ def shard_range(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return b, b + q + (1 if rank < r else 0)
 
 
+STATUS_OK, STATUS_RANGE, STATUS_ERROR = 0, 1, 2
+
+
+class ShardPeerError(RuntimeError):
+    """Another rank's encoder failed in this batch (its own process carries the original exception)."""
+
+
+class ShardPeerRangeError(ShardPeerError, OverflowError):
+    """Another rank's handle reported RR_ERR_RANGE (OverflowError there): the batch's logits are unreliable on every rank."""
+
+
 class _GatherPlan:
-    """Preallocated buffers of one (device, dtype, world, n_pairs, n_heads) exchange."""
+    """Preallocated buffers of one (device, dtype, world, n_pairs, n_heads) exchange.  A rank's block is
+    [head 0: per | head 1: per | status word]."""
 
     def __init__(self, device, dtype, world: int, n_pairs: int, heads: int):
         self.world, self.n, self.heads = world, n_pairs, heads
         self.per = -(-n_pairs // world)                                  # ceil(N / W): the padded slice length
+        self.blk = heads * self.per + 1                                  # + the status word
         self.host = None
-        self.send = torch.zeros(heads * self.per, dtype=dtype, device=device)
-        self.recv = torch.empty(world * heads * self.per, dtype=dtype, device=device)
-        self.ragged = n_pairs % world != 0
-        if self.ragged:      # compaction map: full[h][i] = recv[rank(i), h, i - begin(rank)] — one index_select, no cat
-            idx = torch.empty(heads, n_pairs, dtype=torch.int64)
-            for r in range(world):
-                b, e = shard_range(n_pairs, r, world)
-                for h in range(heads):
-                    idx[h, b:e] = torch.arange(e - b) + (r * heads + h) * self.per
-            self.index = idx.reshape(-1).to(device)
-            self.full = torch.empty(heads * n_pairs, dtype=dtype, device=device)
+        self.send = torch.zeros(self.blk, dtype=dtype, device=device)
+        self.recv = torch.empty(world * self.blk, dtype=dtype, device=device)
+        # compaction map: full[h][i] = recv[rank(i), h, i - begin(rank)], then the `world` status words — one index_select, no cat
+        idx = torch.empty(heads, n_pairs, dtype=torch.int64)
+        for r in range(world):
+            b, e = shard_range(n_pairs, r, world)
+            for h in range(heads):
+                idx[h, b:e] = torch.arange(e - b) + r * self.blk + h * self.per
+        status = torch.arange(world, dtype=torch.int64) * self.blk + (self.blk - 1)
+        self.index = torch.cat([idx.reshape(-1), status]).to(device)
+        self.full = torch.empty(heads * n_pairs + world, dtype=dtype, device=device)
+        self.status_host = torch.empty(world, dtype=dtype, device="cpu")
+        if torch.device(device).type == "cuda":
+            self.status_host = self.status_host.pin_memory()
 
 
 _PLANS: "OrderedDict[tuple, _GatherPlan]" = None      # small LRU: a serving loop sees a handful of batch sizes (the full one, the last one)
@@ -67,9 +92,11 @@ def _plan(device, dtype, world, n_pairs, heads, group=None) -> _GatherPlan:
     return p
 
 
-def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optional[torch.Tensor] = None):
+def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optional[torch.Tensor] = None, status: int = STATUS_OK,
+                  want_status: bool = False):
     """All-gather the ragged per-rank logit slices (and, for the two-head variant, the second head's) into the full
-    [n_pairs] vector(s) with ONE collective.  Returns (full, full2 | None); the tensors are views of buffers that the
+    [n_pairs] vector(s) with ONE collective.  Returns (full, full2 | None) — and, with `want_status`, the `world` status
+    words every rank sent (a device tensor of the logits' dtype) as a third element; the tensors are views of buffers that the
     next call with the same shape overwrites."""
     world = dist.get_world_size(group)
     heads = 1 if local2 is None else 2
@@ -78,6 +105,7 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
     p.send[:n_loc].copy_(local.reshape(-1))
     if local2 is not None:
         p.send[p.per: p.per + n_loc].copy_(local2.reshape(-1))
+    p.send[p.blk - 1] = float(status)
     if p.send.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal on one GPU (bench.py --rehearse-one-gpu): gloo has no device all-gather, stage through the host
         if p.host is None:
@@ -87,13 +115,50 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
         p.recv.copy_(p.host[1])
     else:
         dist.all_gather_into_tensor(p.recv, p.send, group=group)
-    if not p.ragged:
-        if heads == 1:
-            return p.recv, None                                       # rank-major == pair order: the block IS the vector
-        blk = p.recv.view(world, 2, p.per)
-        return blk[:, 0].reshape(-1), blk[:, 1].reshape(-1)            # two strided copies of N floats
     torch.index_select(p.recv, 0, p.index, out=p.full)
-    return p.full[:n_pairs], (p.full[n_pairs:] if heads == 2 else None)
+    full1, full2 = p.full[:n_pairs], (p.full[n_pairs:2 * n_pairs] if heads == 2 else None)
+    return (full1, full2, p.full[heads * n_pairs:]) if want_status else (full1, full2)
+
+
+_DEFERRED = []       # (pinned host copy of a batch's status words, event | None, rank)
+
+
+def _defer_status(st: torch.Tensor, rank: int):
+    host = torch.empty(st.numel(), dtype=st.dtype, device="cpu")
+    ev = None
+    if st.is_cuda:
+        host = host.pin_memory()
+        host.copy_(st, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    else:
+        host.copy_(st)
+    _DEFERRED.append((host, ev, rank))
+
+
+def check_deferred_status():
+    """Raise what the peers of earlier `defer_status` batches reported (every rank holds the same words, so every rank raises
+    here together, or none does).  Waits only for the copies of those batches."""
+    while _DEFERRED:
+        host, ev, rank = _DEFERRED.pop(0)
+        if ev is not None:
+            ev.synchronize()
+        _raise_collectively(host.tolist(), rank, None)
+
+
+def _raise_collectively(status_words, rank: int, own: Optional[BaseException]):
+    """Every rank sees the same status words, so every rank raises (or none does)."""
+    bad = [(r, int(s)) for r, s in enumerate(status_words) if int(s) != STATUS_OK]
+    if not bad:
+        return
+    if own is not None:
+        raise own
+    ranks = [r for r, _ in bad]
+    if all(s == STATUS_RANGE for _, s in bad):
+        raise ShardPeerRangeError(f"rank(s) {ranks} reported an activation-range error (RR_ERR_RANGE) in this batch; "
+                                  f"this rank ({rank}) discards the gathered logits")
+    raise ShardPeerError(f"rank(s) {ranks} failed in their encoder in this batch (status {dict(bad)}); this rank ({rank}) "
+                         f"discards the gathered logits")
 
 
 class ShardedReranker:
@@ -101,19 +166,37 @@ class ShardedReranker:
     `head(logits, logits2) -> dict` into the sharded forward.  `RerankEngine` provides both on the GPU; the gloo CPU
     tests plug in a CPU stand-in engine to cover the slicing / gather / head plumbing."""
 
-    def __init__(self, encode: Callable, head: Callable, group=None):
-        self.encode, self.head, self.group = encode, head, group
+    def __init__(self, encode: Callable, head: Callable, group=None, two_heads: Optional[bool] = None, empty: Optional[Callable] = None,
+                 defer_status: bool = False):
+        """`empty(n) -> tensor` makes the zero slice a failing rank sends (device / dtype of the logits); `two_heads` tells
+        whether that rank must send a second head (both are only needed when `encode` can raise)."""
+        self.encode, self.head, self.group, self.two_heads, self.empty = encode, head, group, two_heads, empty
+        self.defer_status = defer_status
 
     def __call__(self, n_pairs: int):
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        check_deferred_status()             # what the previous batch's peers reported, before this batch's collective
         b, e = shard_range(n_pairs, rank, world)
-        l1, l2 = self.encode(b, e)
-        full1, full2 = gather_logits(l1, n_pairs, self.group, l2)
+        own, status = None, STATUS_OK
+        try:
+            l1, l2 = self.encode(b, e)
+        except Exception as ex:      # noqa: BLE001 — the exchange must still happen on this rank (see the module docstring)
+            if self.empty is None:
+                raise
+            own, status = ex, (STATUS_RANGE if isinstance(ex, OverflowError) else STATUS_ERROR)
+            l1 = self.empty(e - b)
+            l2 = self.empty(e - b) if self.two_heads else None
+        full1, full2, st = gather_logits(l1, n_pairs, self.group, l2, status=status, want_status=True)
+        if self.defer_status and own is None:
+            _defer_status(st, rank)
+        else:
+            _raise_collectively(st.tolist(), rank, own)   # one host read of `world` floats per batch
         return self.head(full1, full2)
 
 
 def sharded_forward(engine, input_ids, attention_mask, token_type_ids, Bq: int, K: int, image_cls=None,
-                    image_patches=None, labels: Optional[torch.Tensor] = None, group=None, want_scores=False):
+                    image_patches=None, labels: Optional[torch.Tensor] = None, group=None, want_scores=False,
+                    defer_status: bool = False):
     """One rerank batch over all ranks of `group` with `engine` (a RerankEngine) on each rank.  Every rank holds the
     whole id tensors (they are 3 x 8 B per token — 1.2 MB per query of 100 x 512 — against ~10 TFLOP of encoder work) and
     encodes only its pair slice; image-derived per-query work is done for the queries the slice touches."""
@@ -137,4 +220,7 @@ def sharded_forward(engine, input_ids, attention_mask, token_type_ids, Bq: int, 
             out["logits2"] = l2.clone()
         return out
 
-    return ShardedReranker(encode, head, group)(N)
+    def empty(n):
+        return torch.zeros(n, dtype=torch.float32, device=input_ids.device)
+
+    return ShardedReranker(encode, head, group, two_heads=two_heads, empty=empty, defer_status=defer_status)(N)

@@ -477,7 +477,14 @@ FULLSIZE = {
     "c5_sep": (dict(hidden=1024, layers=24, heads=16, intermediate=4096, ce_hidden=1024, ce_heads=16,
                     ce_intermediate=4096), False, 512, 300),
 }
-SEP = {"c3_sep": dict(K=100, gap=0.08), "c5_sep": dict(K=200, gap=float(os.environ.get("RR_C5_SEP_GAP", "0.12")))}
+_LARGE = FULLSIZE["c5_sep"]
+# the same construction at lower gains, and at gain 2.5 with the WIDEST gap a pool of 300 allows for K = 200
+# (the 100 candidates behind fp32 rank 5 are left out), so that every fixture carries what the reference's own bf16-autocast
+# arithmetic does on it.  `gap_rel` = designed gap as a fraction of the pool's logit standard deviation (c5_sep: 0.12 / 0.28).
+FULLSIZE.update({"c5_sep_g20": _LARGE, "c5_sep_g15": _LARGE, "c5_sep_wide": _LARGE})
+SEP = {"c3_sep": dict(K=100, gap=0.08), "c5_sep": dict(K=200, gap=float(os.environ.get("RR_C5_SEP_GAP", "0.12"))),
+       "c5_sep_g20": dict(K=200, gap_rel=0.4, gain=2.0), "c5_sep_g15": dict(K=200, gap_rel=0.4, gain=1.5),
+       "c5_sep_wide": dict(K=200, widest=True, pool_of="c5_sep")}
 
 
 def run_fullsize_case(name, outdir):
@@ -494,7 +501,7 @@ def run_fullsize_case(name, outdir):
     kw, vision, S, pool = FULLSIZE[name]
     cfg = O.OracleConfig(**kw)
     cfg.loss_fn = "BCE"
-    gain = 2.5 if name in SEP else 1.0
+    gain = SEP[name].get("gain", 2.5) if name in SEP else 1.0
     w = O.make_weights(cfg, seed=0, vision=vision, gain=gain)
     hf = HFAssembly(cfg, w, vision)
     nq = 2 if name in SEP else 1
@@ -508,19 +515,25 @@ def run_fullsize_case(name, outdir):
         import time
         t0 = time.time()
         cache = os.environ.get("RR_GOLDEN_POOL_CACHE")       # re-select a list (another gap) without the hour of CPU forwards
-        cache = os.path.join(cache, f"{name}_q{qi}_pool_fp32.pt") if cache else None
+        pool_name = SEP.get(name, {}).get("pool_of", name)       # c5_sep_wide re-selects from c5_sep's pool: same logits
+        cache_ac = os.path.join(cache, f"{pool_name}_q{qi}_pool_autocast.pt") if cache else None
+        cache = os.path.join(cache, f"{pool_name}_q{qi}_pool_fp32.pt") if cache else None
+        chunk = 50 if kw.get("hidden", 768) > 768 else 100
         if cache and os.path.exists(cache):
             fp32 = torch.load(cache)
         else:
-            fp32 = _hf_logits_chunked(hf, ids, am, tt, pool, img, chunk=50 if name == "c5_sep" else 100)
+            fp32 = _hf_logits_chunked(hf, ids, am, tt, pool, img, chunk=chunk)
             if cache:
                 torch.save(fp32, cache)
         t1 = time.time()
-        if name == "c5_sep":        # the reference's bf16-autocast pass is not needed by this fixture (640 more bert-large pairs on the CPU)
-            ac = torch.full_like(fp32, float("nan"))
+        # the reference's own arithmetic (bf16 autocast) on the same pool: the yardstick of every reduced-precision mode
+        if cache_ac and os.path.exists(cache_ac):
+            ac = torch.load(cache_ac)
         else:
             with cuda_autocast_emulation():
-                ac = _hf_logits_chunked(hf, ids, am, tt, pool, img)
+                ac = _hf_logits_chunked(hf, ids, am, tt, pool, img, chunk=chunk)
+            if cache_ac:
+                torch.save(ac, cache_ac)
         print(f"[{name} q{qi}] pool of {pool}: fp32 {t1 - t0:.0f} s, autocast {time.time() - t1:.0f} s; "
               f"|autocast - fp32| max {(ac - fp32).abs().max():.3e}; logit std {fp32.std():.3f}")
         rec[f"q{qi}.seed"] = seed
@@ -528,12 +541,18 @@ def run_fullsize_case(name, outdir):
         rec[f"q{qi}.pool_logits"] = fp32.numpy()
         rec[f"q{qi}.pool_logits_autocast"] = ac.numpy()
         if name in SEP:
-            Ksel, gap = SEP[name]["K"], SEP[name]["gap"]
+            Ksel = SEP[name]["K"]
             order = sorted(range(pool), key=lambda i: -fp32[i].item())
             top5 = order[:5]
-            j = 5
-            while j < pool and fp32[order[4]] - fp32[order[j]] < gap:
-                j += 1
+            if SEP[name].get("widest"):
+                j = pool - (Ksel - 5)
+                gap = float(fp32[order[4]] - fp32[order[j]])
+            else:
+                gap = SEP[name]["gap"] if "gap" in SEP[name] else round(SEP[name]["gap_rel"] * float(fp32.std()), 3)
+                j = 5
+                while j < pool and fp32[order[4]] - fp32[order[j]] < gap:
+                    j += 1
+            rec[f"q{qi}.gap_design"] = np.array(gap, dtype=np.float32)
             rest = order[j:j + Ksel - 5]
             assert len(rest) == Ksel - 5, f"pool too small for a {gap} gap (j={j})"
             rng = np.random.Generator(np.random.PCG64(99 + qi))

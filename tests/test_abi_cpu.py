@@ -17,8 +17,8 @@ def lib():
     return _lib.load()
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "rerank_mi355.h")).read()
+def _declared_functions(header="rerank_mi355.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(rr_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,10 +26,16 @@ def _declared_functions():
 def test_header_symbols_are_exported_and_bound(lib):
     from rmr_amd import _lib
     names = _declared_functions()
-    assert len(names) >= 20
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/rerank_mi355.h but not exported"
-    assert set(names) == set(_lib.EXPORTED), "ctypes table and header disagree"
+    diag = _declared_functions("rerank_mi355_diag.h")
+    assert len(names) >= 20 and len(diag) >= 20 and not set(names) & set(diag)
+    for n in names + diag:
+        assert hasattr(lib, n), f"{n} declared under include/ but not exported"
+    assert set(names) | set(diag) == set(_lib.EXPORTED), "ctypes table and headers disagree"
+    # rerank_mi355.h is the PRODUCT ABI INTEGRATION.md binds; operators, tuning switches, stamps and debug
+    # taps live in rerank_mi355_diag.h
+    assert not [n for n in names if n.startswith(("rr_op_", "rr_util_", "rr_debug")) or n in
+                ("rr_set_tuning", "rr_set_gemm_stagger", "rr_set_gemm_variant", "rr_set_gemm_stamps", "rr_set_attn_stamps",
+                 "rr_set_attn_redo_stats", "rr_set_op_dtype", "rr_set_debug")]
 
 
 def test_gemm_objects_hold_no_packed_f32(lib):

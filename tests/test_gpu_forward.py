@@ -578,6 +578,10 @@ def test_two_handles_in_one_process_may_differ_in_their_numerics_options():
     for k, v in pinned.items():
         a.set_option(k, v)
     assert all(a.get_option(k) == v for k, v in pinned.items()) and all(b.get_option(k) == 1 for k in pinned)
+    assert a.get_option("attn_fixed_ref") == 3          # unpinned: the EFFECTIVE (process-wide) attention schedule mode, not -1
+    a.set_option("attn_fixed_ref", 0)
+    assert a.get_option("attn_fixed_ref") == 0 and b.get_option("attn_fixed_ref") == 3
+    a.set_option("attn_fixed_ref", -1)
     with pytest.raises(ValueError):
         a.set_option("no_such_option", 1)
     with pytest.raises(ValueError):

@@ -112,3 +112,31 @@ def test_range_error_is_sticky_for_callers_that_never_poll():
     torch.cuda.synchronize()
     with pytest.raises(OverflowError):
         bad.forward_ids(*args)
+
+
+def test_a_bf16_handle_is_not_refused_for_values_fp16_could_not_hold():
+    """the 9e8 sum-of-squares limit belongs to fp16 operand rows.  A bf16 handle has fp32's exponent range: the same
+    3e4 outlier that makes the fp16 handle sticky-fail above is an ordinary value there — its flag stays clear and every later
+    forward keeps running and reproduces itself; only a NON-FINITE row raises a bf16 handle's flag."""
+    cfg = load_golden("c2")["cfg"]
+    eng = _engine(cfg, _outlier_weights(cfg, ((7, 3.0e4),), compensate=False), "bf16")
+    Bq, K, S = 1, 4, 64
+    ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=5)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K)
+    r1 = eng.forward_ids(*args)
+    torch.cuda.synchronize()
+    r2 = eng.forward_ids(*args)                      # not refused
+    r3 = eng.forward_ids(*args)
+    torch.cuda.synchronize()
+    assert torch.isfinite(r1["logits"]).all() and torch.equal(r1["logits"], r2["logits"]) and torch.equal(r2["logits"], r3["logits"])
+    assert not eng.activation_range_exceeded()
+    # a non-finite row is still an error, also in bf16
+    w = _outlier_weights(cfg, ((7, 3.0e4),), compensate=False)
+    key = next(k for k in w if k.endswith("word_embeddings.weight"))
+    w[key] = w[key].clone()
+    w[key][int(ids[0, 3])] = float("inf")
+    nan = _engine(cfg, w, "bf16")
+    nan.forward_ids(*args)
+    torch.cuda.synchronize()
+    with pytest.raises(OverflowError, match="not finite"):
+        nan.forward_ids(*args)

@@ -147,3 +147,98 @@ def test_sharded_forward_with_an_engine_matches_single_rank(Bq, K, loss_fn):
         if loss_fn == "2H_BCE":
             assert l2 == ref["logits2"].tolist()
         assert order == want_order
+
+
+# ---- world size 8: the width BASELINE configs[3] names (/root/reference/submit_test_jobs.py:74 launches one process per GPU) ----
+def _run_world(target, world, args, timeout=240):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda t: t[0])
+
+
+@pytest.mark.parametrize("Bq,K,loss_fn", [(1, 100, "BCE"), (64, 100, "negative_sampling"), (2, 100, "2H_BCE")])
+def test_eight_ranks_through_sharded_forward(Bq, K, loss_fn):
+    """world 8 over gloo through sharded_forward: one query of K = 100 (the 13/12-pair ragged split of configs[2] strong-scaled,
+    SURVEY 8e), configs[3]'s 64 queries x 100 = 6 400 pairs (800 per rank, listwise head) and the two-head variant."""
+    world = 8
+    res = _run_world(_engine_worker, world, (Bq, K, loss_fn))
+    ids = torch.randint(1, 1000, (Bq * K, 16), generator=torch.Generator().manual_seed(3))
+    ref = _CpuEngine(loss_fn).forward_ids(ids, ids, ids, Bq, K, None, None, None, pair_range=(0, Bq * K))
+    want = ref["logits2"] if loss_fn == "2H_BCE" else ref["logits"]
+    want_order = [O.rank_descending_stable(r) for r in want.view(Bq, K).tolist()]
+    assert [r for r, *_ in res] == list(range(world))
+    from rmr_amd import shard_range
+    sizes = [e - b for b, e in (shard_range(Bq * K, r, world) for r in range(world))]
+    assert sum(sizes) == Bq * K and (sizes == [13, 13, 13, 13, 12, 12, 12, 12] if Bq * K == 100 else max(sizes) - min(sizes) <= 1)
+    for rank, l1, l2, order in res:
+        assert l1 == ref["logits"].tolist()
+        if loss_fn == "2H_BCE":
+            assert l2 == ref["logits2"].tolist()
+        assert order == want_order
+
+
+class _FailingEngine(_CpuEngine):
+    """Stand-in whose forward raises on ONE rank, as RerankEngine does for a handle with the sticky RR_ERR_RANGE
+    (rmr_amd/_lib.py maps it to OverflowError) — a rank-local event, because it depends on the rank's own pair slice."""
+
+    def __init__(self, loss_fn, fail, exc):
+        super().__init__(loss_fn)
+        self.fail, self.exc = fail, exc
+
+    def forward_ids(self, *a, **kw):
+        if self.fail:
+            raise self.exc("RR_ERR_RANGE stand-in" if self.exc is OverflowError else "encoder failed")
+        return super().forward_ids(*a, **kw)
+
+
+def _failing_worker(rank, world, port, bad_rank, exc_name, defer, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rmr_amd.sharding import ShardPeerError, check_deferred_status, sharded_forward
+        exc = {"OverflowError": OverflowError, "ValueError": ValueError}[exc_name]
+        Bq, K = 2, 7
+        ids = torch.randint(1, 1000, (Bq * K, 16), generator=torch.Generator().manual_seed(3))
+        ok = _CpuEngine("BCE")
+        out = sharded_forward(ok, ids, ids, ids, Bq, K)                              # a healthy batch first
+        first = out["logits"].tolist()
+        eng = _FailingEngine("BCE", rank == bad_rank, exc)
+        raised = None
+        try:
+            sharded_forward(eng, ids, ids, ids, Bq, K, defer_status=defer)
+            if defer:
+                check_deferred_status()
+        except Exception as ex:      # noqa: BLE001
+            raised = (type(ex).__name__, isinstance(ex, OverflowError), isinstance(ex, ShardPeerError), str(ex))
+        # nobody is stuck in a collective: the group still works afterwards, and so does the next healthy batch
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        again = sharded_forward(ok, ids, ids, ids, Bq, K)["logits"].tolist()
+        q.put((rank, raised, float(t), first == again))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exc_name,defer", [("OverflowError", False), ("ValueError", False), ("OverflowError", True)])
+def test_an_error_on_one_rank_is_raised_on_every_rank(exc_name, defer):
+    """the sticky range error is rank-local; the exchange carries one status word per rank, the failing rank still
+    takes part, and every rank raises after the gather (the failing one its own exception, its peers ShardPeerError — an
+    OverflowError too when the peer's was) instead of waiting in a collective one rank never enters."""
+    world, bad = 3, 1
+    res = _run_world(_failing_worker, world, (bad, exc_name, defer), timeout=120)
+    for rank, raised, total, same in res:
+        assert raised is not None, f"rank {rank} did not raise"
+        name, is_overflow, is_peer, msg = raised
+        if rank == bad:
+            assert name == exc_name and not is_peer
+        else:
+            assert is_peer and "[1]" in msg and is_overflow == (exc_name == "OverflowError")
+        assert total == 3.0 and same
