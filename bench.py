@@ -182,6 +182,48 @@ def archived_pmc():
     return out
 
 
+def archived_fp8_ranking(first_layer, qkv, down):
+    """`ranking` block of the --fp8 line: what the e4m3 configuration of THIS run does to the fp32 reference's top-5
+    on the committed bert-large ranking fixtures, next to what the reference's own bf16-autocast arithmetic does on the same lists.
+    Archived from the device study (tests/tools/fp8_subset_study.py -> profiles/*_fp8_subset_study.json, seeded random-init weights; the
+    GPU tests assert the same verdicts live: tests/test_gpu_fp8.py); not measured inside this process (the fixtures' generator is test
+    infrastructure).  ranks_with_margin := on every list where the rule binds (the autocast reference keeps the fp32 top-5 with
+    max |d| <= gap / 4) the top-5 set is kept and the centred drift is <= half the designed rank-5/6 gap."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fp8_subset_study.json")))
+    if not files:
+        return {"note": "no archived study under profiles/"}
+    d = json.load(open(files[-1]))
+    tag = f"first{first_layer}_qkv{qkv}_down{down}"
+    lists, binding_ok, binding = {}, True, 0
+    for k, v in d.items():
+        fixture, q, t = k.split("/")
+        if t != tag:
+            continue
+        ref = d.get(f"{fixture}/{q}/reference_autocast", {})
+        lists[f"{fixture}/{q}"] = {"rule_binds": v["rule_binds"], "top5_set_kept": v["top5_set_kept"], "max_abs": v["max_abs"],
+                                   "centred": v["centred"], "rho": v["rho"], "gap_5_6": v["gap_5_6"],
+                                   "reference_bf16_autocast": {"max_abs": ref.get("max_abs"), "centred": ref.get("centred"),
+                                                               "top5_set_kept": ref.get("top5_set_kept")}}
+        if v["rule_binds"]:
+            binding += 1
+            binding_ok = binding_ok and v["top5_set_kept"] and v["centred"] <= 0.5 * v["gap_5_6"]
+    out = {"configuration": {"fp8_first_layer": first_layer, "fp8_qkv": qkv, "fp8_ffn_down": down}, "source": os.path.relpath(files[-1], ROOT),
+           "note": "archived device study on the committed ranking fixtures (seeded random-init bert-large, Linear matrices widened x1.5 - x2.5); "
+                   "not measured in this run"}
+    if not lists:
+        out["verdict"] = "this configuration is not in the archived study"
+        return out
+    out["lists"] = lists
+    out["binding_lists"] = binding
+    out["ranks_with_margin"] = bool(binding and binding_ok)
+    worst = max(lists.values(), key=lambda x: x["centred"] / x["gap_5_6"])
+    out["verdict"] = ("keeps the fp32 top-5 with margin on every list the reference's own bf16 arithmetic ranks" if out["ranks_with_margin"] else
+                      f"DOES NOT RANK on the fixtures: worst centred drift {worst['centred']:.3f} against a rank-5/6 gap of {worst['gap_5_6']:.3f} "
+                      f"(rank correlation {worst['rho']:.2f}; the reference's own bf16-autocast drift there {worst['reference_bf16_autocast']['centred']:.3f})")
+    return out
+
+
 def host_cores():
     """CPU threads this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
     try:
@@ -379,7 +421,7 @@ def main():
         names = {"c3": "c3: FLMR multimodal query cross-encoder rerank (monoPreFLMR-B shape, Lc=1), pointwise BCE head",
                  "c4": "c4: listwise rerank head (negative_sampling: softmax over K) on the c3 encoder",
                  "c5": "c5: bert-large cross-encoder rerank (24 layers, hidden 1024, FFN 4096, text-only)"
-                       + (", e4m3 QKV/FFN-up GEMMs" if args.fp8 else ", 16-bit MFMA"),
+                       + (", e4m3 QKV/FFN-up GEMMs in the layers config.fp8_layers names" if args.fp8 else ", 16-bit MFMA"),
                  "L": "L: monoPreFLMR-L geometry (ViT-L/14 features, 288 vision tokens, T=800), pointwise BCE head"}
         res = {
             "metric": "reranked query x candidate pairs/sec at K=100, seq_len=512",
@@ -421,6 +463,12 @@ def main():
         }
         if redo is not None:
             res["attention_redo"] = redo
+        if args.fp8:
+            fl, fq, fd = (eng.get_option(k) for k in ("fp8_first_layer", "fp8_qkv", "fp8_ffn_down"))
+            res["config"]["fp8_layers"] = (f"e4m3 QKV / FFN-up operands in text-encoder layers {fl}..{arch['layers'] - 1} of {arch['layers']} "
+                                           f"(handle options fp8_first_layer={fl}, fp8_qkv={fq}, fp8_ffn_down={fd}); the shipped default is the last two "
+                                           "layers, the largest subset that ranks with margin; --tuning fp8_first_layer=0 = the whole stack")
+            res["ranking"] = archived_fp8_ranking(fl, fq, fd)
         if prof is not None:
             g = prof["gemm"]
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0

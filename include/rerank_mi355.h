@@ -173,6 +173,13 @@ int rr_reserve(rr_handle h, int n_pairs, int n_queries, int len_a, int len_b, in
  * fp32 summation order.  "Bit for bit" holds while the shorter call's attention grid and the padded call's are on the same
  * side of the 1 024-workgroup threshold between the online and the fixed-reference softmax schedule (a bucket of a few
  * pairs runs the online form: same values up to rounding); rr_forward_packed has no such condition.  0 switches it off.
+ * ROW-COUNT DEPENDENCE OF THE ROUNDINGS (every forward entry point): a GEMM row's values never depend on the rows that share its
+ * launch, but the form the residual stream takes between the two residual epilogues of a layer does — (hi, lo) 16-bit pairs where
+ * the call has at least 128 tiles of 256 x 256 rows x hidden (about 11k rows at hidden 768: the persistent ring runs there),
+ * fp32 rows below.  A bucket, a pair_begin / pair_end slice or a multi-GPU shard under that size therefore agrees with the
+ * large call to the parity tolerance (1e-3 in fp16; measured ~2e-4 on c3_full: tests/test_gpu_parity_fullsize.py,
+ * test_sharded_slices_and_the_whole_list_agree_within_the_parity_gate), not to the bit.  "resid_split" = 0 removes the
+ * dependence (fp32 rows at every size, +3 % time at the bench shape).
  * Python: RerankEngine.forward_ids_bucketed. */
 int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
 
@@ -190,11 +197,14 @@ int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
  *                                                     pair only (all the classifiers read, utils.py:105-108); 0: every row
  *   "fp8_ffn_down"   0 | 1                  0         rr_config.fp8 only: FFN-down on the e4m3 ring too (GELU output as e4m3 under a
  *                                                     static scale of 8); 0: FFN-down keeps 16-bit operands
- *   "fp8_first_layer" 0 .. layers           0         rr_config.fp8 only: text-encoder layers with an index below this value keep
+ *   "fp8_first_layer" 0 .. layers           layers-2  rr_config.fp8 only: text-encoder layers with an index below this value keep
  *                                                     16-bit operands (the folded-LayerNorm dataflow); layers from it on run the
- *                                                     e4m3 configuration.  `layers` = no e4m3 GEMM at all.  A perturbation
- *                                                     injected early is amplified by every later layer, so e4m3 belongs in the
- *                                                     LAST layers first (DESIGN.md "fp8")
+ *                                                     e4m3 configuration.  `layers` (or more) = no e4m3 GEMM at all; 0 = every
+ *                                                     layer (the whole-stack form: 1.13x the 16-bit line on bert-large, and
+ *                                                     MEASURED not to keep the fp32 top-5 on the ranking fixtures — opt in only
+ *                                                     with a checkpoint you have validated).  A perturbation injected early is
+ *                                                     amplified by every later layer, so e4m3 goes into the LAST layers first;
+ *                                                     the default is the largest subset that ranks with margin (DESIGN.md "fp8")
  *   "fp8_qkv"        0 | 1                  1         rr_config.fp8 only: 0 = of an e4m3 layer only the FFN takes e4m3 operands,
  *                                                     its QKV projection keeps 16-bit ones
  *   "attn_fixed_ref" 0 | 1 | 2 | 3          3         softmax schedule of large attention grids: 0 online only, 1 fixed reference

@@ -29,6 +29,16 @@
 #include <cstdlib>
 #include <mutex>
 
+// Diagnostic builds of the split residual epilogue (RR_HIPCC_EXTRA=-DRR_EPI_DIAG=n, never in a product build): bit 0 = its stores
+// happen only for a value that never occurs, bit 1 = its residual loads are replaced by register constants, bit 2 = no LayerNorm
+// statistics (no cross-lane sums, no partial store) — what each part costs the launch (profiles/r05_e_*).
+#ifndef RR_EPI_DIAG
+#define RR_EPI_DIAG 0
+#endif
+// (Round 5: requesting the residual rows TWO passes ahead — two register sets of 32, the first two requests before the accumulator
+// arithmetic — was built and not run: hipcc spills 69 VGPRs / 232 B of scratch at 256 registers, and a scratch access is a
+// vector-memory operation that queues behind the prefetch DMA.)
+
 namespace {
 
 constexpr int BK = 64;
@@ -1324,7 +1334,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         for (int u = 0; u < UN8; ++u) {
           const int gm = rbase_ + (tid >> 5) + u * 16;
           const bool ok = gm < M && col_ok8;
-          if constexpr ((SPLIT & 1) != 0) {
+          if constexpr ((SPLIT & 1) != 0 && (RR_EPI_DIAG & 2) != 0) {
+            rh[u] = make_uint4(0x3c003c00u + gm, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+            rl[u] = make_uint4(0x10001000u + tid, 0x10001000u, 0x10001000u, 0x10001000u);
+          } else if constexpr ((SPLIT & 1) != 0) {
             rh[u] = ok ? load_stream_u4(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
             rl[u] = ok ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
           } else {
@@ -1425,7 +1438,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           uint32_t hi[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
-          if (ok) {
+          bool st_ok = ok;
+          if constexpr ((RR_EPI_DIAG & 1) != 0) st_ok = ok && f[0] == 1.2345e38f;
+          if (st_ok) {
             if constexpr (SPLIT != 4) store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint4(hi[0], hi[1], hi[2], hi[3]));
             if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
               uint32_t lo[4];
@@ -1446,7 +1461,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             }
           }
           // LayerNorm statistics of the 128-column group = the 16 lanes of this DPP row (every lane takes part)
-          if constexpr (SPLIT != 4) {           // (SPLIT 4: the plain fp32 stream on this epilogue — no 16-bit copy, no statistics)
+          if constexpr (SPLIT != 4 && (RR_EPI_DIAG & 4) == 0) {           // (SPLIT 4: the plain fp32 stream on this epilogue — no 16-bit copy, no statistics)
             const int grp = gcol >> 7;
             const float rcnt = __builtin_amdgcn_rcpf((float)max(1, min(128, N - (grp << 7))));
             const float mg = row16_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) * rcnt;
@@ -1456,7 +1471,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
               for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
             }
             const float m2 = row16_sum(q);
-            if (ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
+            if (st_ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
           }
         }
         EP_ADD(8)
@@ -1590,6 +1605,13 @@ inline int device_cus() {
   if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
   return n;
 }
+// diagnostic (rr_set_tuning "gemm_grid_cus"): the persistent kernels run on this many CUs only (a multiple of 8; 0 = all) — what an
+// epilogue costs when fewer CUs share the memory system (tools/gemm_epilogue_timeline.py --tuning gemm_grid_cus=128)
+std::atomic<int> g_grid_cus{0};
+inline int persistent_cus() {
+  const int n = device_cus(), lim = g_grid_cus.load();
+  return lim >= 8 && lim < n ? (lim & ~7) : n;
+}
 
 int g_stagger = 0;                        // start-skew unit in s_sleep(127) steps (rr_set_gemm_stagger)
 std::atomic<int> g_resid_fast{1};         // rr_set_tuning("resid_fast"): plain fp32 residual GEMMs on the split forms' epilogue (SPLIT 4)
@@ -1611,7 +1633,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
                      int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   if (N & 7) return hipErrorInvalidValue;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
-  const int n_cu = device_cus();
+  const int n_cu = persistent_cus();
   if (n_cu < 8) return hipErrorInvalidValue;
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(nwg < n_cu ? ((nwg + 7) & ~7) : n_cu), block(512);
@@ -1693,7 +1715,7 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
                           int ldr, void* C, int ldc, int M, int N, int Kd, int epilogue, hipStream_t st, LnResid ln) {
   if (N & 7) return hipErrorInvalidValue;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256, nwg = tiles_m * tiles_n;
-  const int n_cu = device_cus();
+  const int n_cu = persistent_cus();
   if (n_cu < 8 || nwg < n_cu) return hipErrorInvalidValue;
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(n_cu), block(512);
@@ -1848,6 +1870,9 @@ std::atomic<int> g_resid_split{1};       // rr_set_tuning("resid_split")
 // the ring wins from ~150 tiles on (one tile per CU on 60 % of the chip beats three 128 x 128 tiles per CU: QKV 26 vs 37 us at
 // 234 tiles, attention-out 33 vs 43 us at 150) and loses at 78 (28 vs 24 us).  Rounds 1-3 used 512.
 std::atomic<int> g_ring_min_tiles{128};  // rr_set_tuning("gemm_ring_min_tiles")
+std::atomic<int> g_small_half_rows{1};   // rr_set_tuning("gemm_small_half_rows"): 64 x 128 tiles below two 128 x 128 workgroups per CU
+extern "C" int rr_set_gemm_small_half_rows(int on) { g_small_half_rows.store(on != 0); return 0; }
+extern "C" int rr_set_gemm_grid_cus(int n) { g_grid_cus.store(n < 0 ? 0 : n); return 0; }
 extern "C" int rr_set_gemm_ring_min_tiles(int n) { if (n < 1) return -1; g_ring_min_tiles.store(n); return 0; }
 extern "C" int rr_set_resid_split(int on) { g_resid_split.store(on != 0); return 0; }
 extern "C" int rr_get_resid_split(void) { return g_resid_split.load(); }
@@ -1905,6 +1930,15 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     v = tiles256 >= g_ring_min_tiles.load() ? ((N & 7) ? 11 : (g_persistent ? 14 : 12)) : 0;   // 14: persistent ring (one workgroup per CU walks its tiles)
   }
+  // Below the ring: 64 x 128 tiles where 128 x 128 ones leave the chip less than two workgroups per CU (the strong-scaling shard
+  // shapes of one K = 100 query: 13 pairs = 312 tiles of 128 x 128 on 256 CUs, i.e. 56 CUs with two tiles and 200 with one; halved
+  // tiles balance 624 over the chip — attention-out 24 -> 21 us, FFN-down 51 -> 49 us, profiles/r04 "64 x 128").
+  // A row's values do not depend on the tile shape (same K walk per column, same accumulation order), so this moves time only.
+  bool half_rows = false;
+  if (v == 0) {
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    half_rows = g_small_half_rows.load() && tiles128 < 2L * (device_cus() > 0 ? device_cus() : 256);
+  }
   if (fold.x16) {   // the producer side of the folded LayerNorm lives in the LDS-staged epilogues only
     if (v == 0) v = 20;
     else if (v != 10 && v != 12 && v != 14 && v != 15 && v != 20) return hipErrorInvalidValue;
@@ -1912,8 +1946,12 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
   if (split && v != 14 && v != 15) return hipErrorInvalidValue;     // the split residual stream lives in the persistent ring kernel only
   if (dt == 1) {   // fp16 operands: the production configurations only
     switch (v) {
-      case 0: return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
-      case 20: return launch_cfg<128, 128, 2, 2, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 0:
+        if (half_rows) return launch_cfg<64, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+        return launch_cfg<128, 128, 2, 2, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      case 20:
+        if (half_rows) return launch_cfg<64, 128, 2, 2, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+        return launch_cfg<128, 128, 2, 2, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 2: return launch_cfg<256, 256, 2, 4, 2, false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 10: return launch_cfg<256, 256, 2, 4, 2, true, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
       case 11: return launch_h<false, 1>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
@@ -1926,8 +1964,12 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
 #define RR_CFG(BM_, BN_, WM_, WN_, ST_) \
   return launch_cfg<BM_, BN_, WM_, WN_, ST_>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln)
   switch (v) {
-    case 0: RR_CFG(128, 128, 2, 2, 2);
-    case 20: return launch_cfg<128, 128, 2, 2, 2, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+    case 0:
+      if (half_rows) RR_CFG(64, 128, 2, 2, 2);
+      RR_CFG(128, 128, 2, 2, 2);
+    case 20:
+      if (half_rows) return launch_cfg<64, 128, 2, 2, 2, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
+      return launch_cfg<128, 128, 2, 2, 2, true>(A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd, epilogue, st, ln);
     case 1: RR_CFG(128, 128, 2, 2, 4);
     case 2: RR_CFG(256, 256, 2, 4, 2);
     case 3: RR_CFG(256, 128, 4, 2, 3);

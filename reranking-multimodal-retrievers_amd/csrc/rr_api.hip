@@ -713,6 +713,8 @@ extern "C" int rr_set_attn_prio(int on);
 extern "C" int rr_set_attn_fixed_ref(int on);
 extern "C" int rr_set_resid_fast(int on);
 extern "C" int rr_set_gemm_ring_min_tiles(int n);
+extern "C" int rr_set_gemm_small_half_rows(int on);
+extern "C" int rr_set_gemm_grid_cus(int n);
 extern "C" int rr_set_resid_split(int on);
 extern "C" int rr_set_gemm_desync(int pct);
 extern "C" int rr_set_m_alternate(int on);
@@ -747,7 +749,12 @@ struct ResidSrc {
 
 int g_ce_cls_only = 1;                   // tuning (rr_set_tuning "ce_cls_only"): 1 = the cross-encoder's last layer computes the CLS rows only
 int g_fp8_ffn_down = 0;                  // tuning (rr_set_tuning "fp8_ffn_down"): 1 = FFN-down of the fp8 configuration on the e4m3 ring too (opt-in: ADVICE r3, DESIGN.md "fp8")
-int g_fp8_first_layer = 0;               // tuning / option "fp8_first_layer": text-encoder layers below this index keep 16-bit operands in the fp8 configuration
+// tuning / option "fp8_first_layer": text-encoder layers below this index keep 16-bit operands in the fp8 configuration.
+// -1 (default) = layers - FP8_SAFE_LAYERS: the subset that keeps the fp32 top-5 with margin on every ranking fixture whose list the
+// reference's own bf16-autocast arithmetic ranks (tests/test_gpu_fp8.py, profiles/r05_fp8_subset_study.json; DESIGN.md "fp8")
+int g_fp8_first_layer = -1;
+constexpr int FP8_SAFE_LAYERS = 2;
+inline int fp8_first_layer_of(int opt, int layers) { return opt >= 0 ? (opt < layers ? opt : layers) : (layers > FP8_SAFE_LAYERS ? layers - FP8_SAFE_LAYERS : 0); }
 int g_fp8_qkv = 1;                       // tuning / option "fp8_qkv": 0 = only the FFN of an fp8 layer takes e4m3 operands, its QKV projection stays 16-bit
 constexpr float FP8_GELU_MUL = 8.0f;     // static scale of the e4m3 GELU output feeding it
 int g_ln_fold = 1;   // tuning (rr_set_tuning "ln_fold"): 1 = LayerNorm folded into the consumer GEMMs, 0 = LayerNorm kernels
@@ -1573,7 +1580,7 @@ static int forward_full(rr_handle h, const int64_t* input_ids, const int64_t* at
   {
     ResidSrc rs{w.h32, nullptr, nullptr, nullptr};      // embeddings LayerNorm output, materialised
     int folded = OP_NORMALISED;
-    const int fp8_from = c.fp8 ? opt_of(m, RR_OPT_FP8_FIRST_LAYER) : 0;      // layers below it keep 16-bit operands ("fp8_first_layer")
+    const int fp8_from = c.fp8 ? fp8_first_layer_of(opt_of(m, RR_OPT_FP8_FIRST_LAYER), c.layers) : 0;   // layers below it keep 16-bit operands
     for (int l = 0; l < c.layers; ++l)                    // the last layer's normalised rows feed the 768 -> 128 projection
       RR_TRY(run_layer(m, st, m->text_layers[l], n, S, Hd, c.heads, I, c.ln_eps, w.text_bias, w, rs, folded,
                        l == c.layers - 1, m->debug, nullptr, 0, tv, c.fp8 ? (l >= fp8_from ? 1 : 0) : -1,
@@ -1955,7 +1962,8 @@ int rr_get_option(rr_handle h, const char* key, int* value_out) {
     // the EFFECTIVE value: opt_of keeps -1 for an unpinned "attn_fixed_ref" (the launcher then takes its process-wide mode);
     // a reader is shown that mode
     const int v = opt_of(h, i);
-    *value_out = (i == RR_OPT_ATTN_FIXED_REF && v < 0) ? rr_get_attn_fixed_ref() : v;
+    *value_out = (i == RR_OPT_ATTN_FIXED_REF && v < 0) ? rr_get_attn_fixed_ref()
+                 : i == RR_OPT_FP8_FIRST_LAYER ? fp8_first_layer_of(v, h->cfg.layers) : v;
     return RR_OK;
   });
 }
@@ -1966,7 +1974,7 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ln_lite")) { g_ln_lite = value != 0; return RR_OK; }
   if (!strcmp(key, "ln_fold")) { g_ln_fold = value != 0; return RR_OK; }
   if (!strcmp(key, "fp8_ffn_down")) { g_fp8_ffn_down = value != 0; return RR_OK; }
-  if (!strcmp(key, "fp8_first_layer")) { g_fp8_first_layer = value < 0 ? 0 : value; return RR_OK; }
+  if (!strcmp(key, "fp8_first_layer")) { g_fp8_first_layer = value < 0 ? -1 : value; return RR_OK; }
   if (!strcmp(key, "fp8_qkv")) { g_fp8_qkv = value != 0; return RR_OK; }
   if (!strcmp(key, "ce_cls_only")) { g_ce_cls_only = value != 0; return RR_OK; }
   if (!strcmp(key, "persistent_gemm")) return rr_set_gemm_persistent(value);
@@ -1974,6 +1982,8 @@ int rr_set_tuning(const char* key, int value) {
   if (!strcmp(key, "resid_split")) return rr_set_resid_split(value);
   if (!strcmp(key, "resid_fast")) return rr_set_resid_fast(value);
   if (!strcmp(key, "gemm_ring_min_tiles")) return rr_set_gemm_ring_min_tiles(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
+  if (!strcmp(key, "gemm_small_half_rows")) { rr_set_gemm_small_half_rows(value); return RR_OK; }
+  if (!strcmp(key, "gemm_grid_cus")) { rr_set_gemm_grid_cus(value); return RR_OK; }
   if (!strcmp(key, "gemm_desync")) return rr_set_gemm_desync(value) == 0 ? RR_OK : RR_ERR_BAD_ARG;
   if (!strcmp(key, "m_alternate")) return rr_set_m_alternate(value);
   if (!strcmp(key, "attn_prio")) return rr_set_attn_prio(value);

@@ -316,8 +316,11 @@ class RerankEngine:
         Bucket sizes: every group is its own forward (~135 launches) over fewer pairs, so few, wide buckets win: measured
         on 800 pairs of length U[64, 512] (bench.py --regime realistic --bucketed): (128, 256, 384) 71.5 ms, (192, 320) 74.8,
         (256,) 77.8, five buckets 77.5, seven 82.1, against 94.5 ms padded.
-        Text-only: logits bit-identical to forward_ids; with vision tokens equal up to fp32 summation order in the
-        cross-encoder's attention.  Returns the dict of forward_ids."""
+        Text-only: logits bit-identical to forward_ids WHILE every bucket and the padded call lie on the same side of two size
+        thresholds (include/rerank_mi355.h, rr_set_padded_seq_len: the 1 024-workgroup attention schedule switch and the
+        128-tile switch between the fp32 and the (hi, lo) residual stream, about 11k rows at hidden 768); across them, and with
+        vision tokens (other key-tile cuts in the cross-encoder's attention), equal to the parity tolerance — 1e-3 in fp16,
+        measured ~2e-4 — not to the bit.  Returns the dict of forward_ids."""
         dev = self.device
         N, S = input_ids.shape
         assert N == Bq * K

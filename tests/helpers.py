@@ -60,6 +60,14 @@ def bf16_gate(name):
     return max(1e-3, 1.5 * autocast_drift(name)[0])
 
 
+def fullsize_bf16_gate(name):
+    """bf16_gate for a FULL-SIZE golden (tests/golden/<name>.npz carries the reference's bf16-autocast logits of its own pool):
+    max(1e-3, 1.5 x max |autocast - fp32|), the rule of bf16_gate.  Reads the fixture only (no weights are built)."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    d = max(float(np.abs(z[f"q{qi}.pool_logits_autocast"] - z[f"q{qi}.pool_logits"]).max()) for qi in range(int(z["nq"])))
+    return max(1e-3, 1.5 * d)
+
+
 def load_fullsize(name):
     """Full-size goldens (make_golden.py run_fullsize_case): returns (cfg, weights, per-query list of dicts with the
     regenerated pool inputs and the stored fp32 / autocast pool logits)."""
@@ -83,6 +91,30 @@ def load_fullsize(name):
                 q[k] = z[f"q{qi}.{k}"]
         qs.append(q)
     return cfg, w, vision, qs
+
+
+RANKING_FIXTURES_C5 = ("c5_sep", "c5_sep_wide", "c5_sep_g20", "c5_sep_g15")      # bert-large ranking fixtures (make_golden.py SEP)
+
+
+def top5_set(t):
+    return set(torch.as_tensor(t).flatten().argsort(descending=True, stable=True)[:5].tolist())
+
+
+def ranking_yardstick(q):
+    """What the REFERENCE's own arithmetic (bf16 autocast, monoPreFLMR-B_pointwise.jsonnet:186,233) does on a ranking fixture's
+    list: (selected pool indices, fp32 logits of the list, autocast logits of the list, designed rank-5/6 gap, margin_stats of
+    autocast vs fp32, autocast keeps the fp32 top-5 set, RULE BINDS).  The rule of VERDICT r4 item 1(b): a reduced-precision
+    mode must keep the fp32 top-5 on every list where the reference's autocast keeps it with max |d| <= gap / 4."""
+    sel = torch.from_numpy(q["selected"].astype(np.int64))
+    ref, ac = q["fp32"][sel], q["autocast"][sel]
+    gap = float(q["gap_5_6"])
+    st = margin_stats(ac, ref)
+    kept = top5_set(ref) == top5_set(ac)
+    # the drift of the reference's arithmetic over the query's whole candidate POOL (300 pairs): the less noisy yardstick for an
+    # absolute-drift bound than the maximum over the 200 selected ones
+    pool = float((q["autocast"] - q["fp32"]).abs().max())
+    return dict(sel=sel, ref=ref, autocast=ac, gap=gap, stats=st, autocast_keeps_top5=bool(kept), pool_autocast_max_abs=pool,
+                binds=bool(kept and st["max_abs"] <= gap / 4))
 
 
 def margin_stats(got, ref):

@@ -254,6 +254,7 @@ def test_fp8_ffn_down_forward_against_the_oracle_emulation():
     arch = arch_from_cfg(cfg, False, "fp16")
     arch["fp8"] = 1
     eng = rmr_amd.RerankEngine(arch)
+    eng.set_option("fp8_first_layer", 0)         # the whole-stack e4m3 form (the shipped default is the last two layers: see the ranking tests)
     eng.load_state_dict(w)
     args = (ids.cuda(), am.cuda(), tt.cuda(), Bq, K)
     eng.set_option("fp8_ffn_down", 1)            # opt-in (a handle option; the default keeps FFN-down in 16 bits)
@@ -294,6 +295,7 @@ def test_fp8_forward_small_model_against_the_oracle_emulation(dt):
     arch = arch_from_cfg(cfg, False, dt)
     arch["fp8"] = 1
     eng = rmr_amd.RerankEngine(arch)
+    eng.set_option("fp8_first_layer", 0)         # the whole-stack e4m3 form (the shipped default is the last two layers: see the ranking tests)
     eng.load_state_dict(w)
     r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K, want_order=True)
     torch.cuda.synchronize()
@@ -313,10 +315,10 @@ def test_fp8_forward_small_model_against_the_oracle_emulation(dt):
     assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
 
 
-# Gates of the e4m3 drift on c5_full, FROZEN at absolute numbers (they used to be 2 x whatever was measured).
-# Default configuration of rr_config.fp8 (e4m3 QKV / FFN-up, 16-bit FFN-down): measured 4.6e-2 abs / 3.9e-2 centred, rank
-# correlation 0.970.  Opt-in "fp8_ffn_down" (GELU output as e4m3 under the static scale 8): 7.8-8.2e-2 / 4.5-4.9e-2, 0.951-0.964.
-# Whether either configuration RANKS like the fp32 reference is what c5_sep decides (test_fp8_ranking_on_c5_sep below).
+# Gates of the e4m3 drift on c5_full for the WHOLE-STACK form ("fp8_first_layer" = 0), FROZEN at absolute numbers since round 4
+# (they used to be 2 x whatever was measured).  e4m3 QKV / FFN-up, 16-bit FFN-down: measured 4.6e-2 abs / 3.9e-2
+# centred, rank correlation 0.970.  Opt-in "fp8_ffn_down" (GELU output as e4m3 under the static scale 8): 7.8-8.2e-2 / 4.5-4.9e-2,
+# 0.951-0.964.  Whether a configuration RANKS like the fp32 reference is what the c5 ranking fixtures decide (the tests below).
 FP8_GATES = {0: dict(abs=0.06, centred=0.05, rho=0.95), 1: dict(abs=0.10, centred=0.06, rho=0.93)}
 
 
@@ -327,6 +329,7 @@ def _fp8_engine(name):
     arch = arch_from_cfg(cfg, vision, "fp16")
     arch["fp8"] = 1
     eng = rmr_amd.RerankEngine(arch)
+    eng.set_option("fp8_first_layer", 0)         # the whole-stack e4m3 form (the shipped default is the last two layers: see the ranking tests)
     eng.load_state_dict(w)
     return eng, qs
 
@@ -358,62 +361,129 @@ def test_fp8_forward_bert_large_against_the_c5_golden():
         assert st["max_abs"] <= gate["abs"] and st["centred"] <= gate["centred"] and st["rho"] >= gate["rho"]
 
 
-def _rank_c5_sep(eng, qs, tag):
-    """(top-5 sets kept per query, Recall@5/10 of the engine, of the fp32 reference) on the c5_sep lists; margins recorded."""
+def _rank_lists(eng, name, qs, tag):
+    """One forward per query of a ranking fixture: per query dict(stats vs fp32, top-5 set kept, yardstick), the engine's and the fp32
+    reference's Recall@5/10; every margin recorded under `<fixture>/q<i>/<tag>` next to the reference's own autocast figures."""
     import rmr_amd
-    from helpers import O, margin_stats, record_margin
-    ranked, ranked_ref, pos, kept = [], [], [], []
+    from helpers import O, margin_stats, ranking_yardstick, record_margin, top5_set
+    ranked, ranked_ref, pos, rows = [], [], [], []
     for qi, q in enumerate(qs):
-        sel = torch.from_numpy(q["selected"].astype(np.int64))
-        ids, am, tt = q["ids"][sel], q["am"][sel], q["tt"][sel]
-        r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), 1, len(sel), want_order=True)
+        y = ranking_yardstick(q)
+        sel, ref = y["sel"], y["ref"]
+        r = eng.forward_ids(q["ids"][sel].cuda(), q["am"][sel].cuda(), q["tt"][sel].cuda(), 1, len(sel), want_order=True)
         torch.cuda.synchronize()
-        lg, ref = r["logits"].cpu(), q["fp32"][sel]
+        lg = r["logits"].cpu()
         order, ref_order = r["order"][0].cpu().tolist(), O.rank_descending_stable(ref.tolist())
         st = margin_stats(lg, ref)
-        gap = float(q["gap_5_6"])
-        ok = set(order[:5]) == set(ref_order[:5])
-        print(f"[c5_sep/{tag} q{qi}] |dlogit| {st['max_abs']:.3e} centred {st['centred']:.3e} rho {st['rho']:.4f} top-5 {st['top5']}; "
-              f"logit std {ref.std():.3f}, rank-5/6 gap {gap:.3f}; top-5 set {'kept' if ok else 'LOST'}")
-        record_margin(f"c5_sep/q{qi}/{tag}", gap_5_6=gap, top5_set_kept=bool(ok), **st)
+        kept = set(order[:5]) == set(ref_order[:5])
+        print(f"[{name}/{tag} q{qi}] |dlogit| {st['max_abs']:.3e} centred {st['centred']:.3e} rho {st['rho']:.4f} top-5 {st['top5']} "
+              f"{'kept' if kept else 'LOST'}; gap {y['gap']:.3f}; reference bf16-autocast: |d| {y['stats']['max_abs']:.3e} centred "
+              f"{y['stats']['centred']:.3e} top-5 {'kept' if y['autocast_keeps_top5'] else 'lost'}; rule {'binds' if y['binds'] else 'does not bind'}")
+        record_margin(f"{name}/q{qi}/{tag}", gap_5_6=y["gap"], top5_set_kept=bool(kept), rule_binds=y["binds"],
+                      reference_autocast_pool_max_abs=y["pool_autocast_max_abs"], reference_autocast_max_abs=y["stats"]["max_abs"], reference_autocast_centred=y["stats"]["centred"],
+                      reference_autocast_keeps_top5=y["autocast_keeps_top5"], **st)
         assert torch.isfinite(lg).all() and order == O.rank_descending_stable(lg.tolist())
-        ranked.append(order); ranked_ref.append(ref_order); pos.append([int(q["positive_list_index"])]); kept.append(ok)
-    return kept, rmr_amd.recall_precision_at_k(ranked, pos, [5, 10]), O.recall_precision_at_k(ranked_ref, pos, [5, 10])
+        assert top5_set(lg) == set(order[:5])
+        ranked.append(order); ranked_ref.append(ref_order); pos.append([int(q["positive_list_index"])])
+        rows.append(dict(stats=st, kept=kept, y=y))
+    return rows, rmr_amd.recall_precision_at_k(ranked, pos, [5, 10]), O.recall_precision_at_k(ranked_ref, pos, [5, 10])
 
 
+def _fixtures():
+    import os
+    from helpers import GOLDEN, RANKING_FIXTURES_C5
+    return [n for n in RANKING_FIXTURES_C5 if os.path.exists(os.path.join(GOLDEN, f"{n}.npz"))]
+
+
+@pytest.mark.parametrize("name", _fixtures())
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-def test_16_bit_ranking_on_c5_sep(dt):
-    """c5_sep = bert-large, widened weights (gain 2.5, as c3_sep), two queries x 200 candidates chosen from a
-    pool of 300 so that the fp32 stock-HF logits leave >= 0.12 between rank 5 and rank 6; query 0's only positive is the fp32
-    rank-5 candidate, query 1's the rank-6 one.  The 16-bit modes must deliver the fp32 reference's top-5 id SETS and
-    Recall@5 = (1, 0), Recall@10 = (1, 1) — fp16 with the drift well inside half the gap (measured 8.5e-3)."""
+def test_16_bit_ranking_on_the_c5_ranking_fixtures(name, dt):
+    """The c5 ranking fixtures (tests/golden/make_golden.py SEP: bert-large, two queries x 200 candidates chosen from a pool of 300
+    so that the fp32 stock-HF logits leave a designed gap between rank 5 and rank 6; gains 2.5 (c5_sep, gap 0.12; c5_sep_wide, the
+    widest gap the pool allows), 2.0, 1.5), each carrying the logits of the REFERENCE's own arithmetic (bf16 autocast) on the same
+    lists.  Gates, every one derived from that yardstick and the designed gap, none from the value observed:
+      * bf16 (the reference's own operand type): max |d| <= 1.5 x the autocast reference's max |d| over the query's candidate POOL
+        (the figure the fixture was generated with; the rule of helpers.bf16_gate: one draw of the same rounding noise against
+        another — the maximum over the 200 selected candidates alone is too noisy a yardstick: on c5_sep_wide q1 it is 0.082 where
+        the pool's is 0.104), and the fp32 top-5 set is kept on every list where
+        the rule binds (autocast keeps it with max |d| <= gap / 4: then 1.5 x that is < gap / 2, so the drift bound itself implies
+        it); on the other lists (the autocast reference's own drift is 0.6 - 0.9 of the gap there: it keeps its top-5 by the draw,
+        not by margin) the outcome is recorded, not gated;
+      * fp16 (3 more mantissa bits = 8 x finer operand rounding): max |d| <= 1/4 of the same pool figure, and the top-5 set
+        kept wherever the autocast reference keeps it — then Recall@5/10 equal the fp32 reference's (1/0 and 1/1 by construction)."""
     import rmr_amd
     from helpers import arch_from_cfg, load_fullsize
-    cfg, w, vision, qs = load_fullsize("c5_sep")
+    cfg, w, vision, qs = load_fullsize(name)
     eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, vision, dt))
     eng.load_state_dict(w)
-    kept, got, want = _rank_c5_sep(eng, qs, dt)
+    rows, got, want = _rank_lists(eng, name, qs, dt)
     assert want["recall"] == [0.5, 1.0]
-    assert all(kept) and got == want
+    for r in rows:
+        ac = r["y"]["pool_autocast_max_abs"]
+        assert r["stats"]["max_abs"] <= (1.5 if dt == "bf16" else 0.25) * ac
+        if r["y"]["binds"] if dt == "bf16" else r["y"]["autocast_keeps_top5"]:
+            assert r["kept"]
+    if all(r["y"]["binds"] if dt == "bf16" else r["y"]["autocast_keeps_top5"] for r in rows):
+        assert got == want
 
 
-@pytest.mark.parametrize("down", [0, 1])
-def test_fp8_ranking_on_c5_sep(down):
-    """The ranking verdict of configs[4] in fp8, on the fixture the 16-bit modes pass above.  MEASURED: the
-    e4m3 configuration does NOT keep the fp32 top-5 on c5_sep — |dlogit| 0.57-0.68 against a logit std of 0.15-0.20, rank
-    correlation 0.44-0.64, top-5 overlap 0-1 of 5, with the 16-bit FFN-down as with the e4m3 one.  A widened random network
-    amplifies a perturbation layer by layer (its fp16 drift is already 10 x that of c5_full); the 3-bit mantissa of e4m3 perturbs
-    every GEMM at the 1e-3 level and 25 layers later the ranking is gone.  Hence: rr_config.fp8 is an opt-in whose drift bench.py
-    and DESIGN.md report, "fp8_ffn_down" is off by default, and no further speed is bought with e4m3 until a trained checkpoint
-    says otherwise.  The test records the outcome and is an EXPECTED failure; it turns into XPASS if a change makes fp8 rank."""
+# The e4m3 configuration on the ranking fixtures.  What the device study found (tests/tools/fp8_subset_study.py,
+# profiles/r05_fp8_subset_study.json): with e4m3 QKV / FFN-up in EVERY layer a widened random bert-large does not keep the fp32
+# top-5 where the reference's own autocast arithmetic does; the drift grows with the number of e4m3 layers (one layer: about the
+# autocast reference's own drift; all 24: 8 x), so the subset that ranks WITH MARGIN is the last two layers.  That subset is the
+# default of rr_config.fp8 (handle option "fp8_first_layer" = layers - 2); the whole-stack form is an opt-in whose verdict is frozen
+# below.  "Ranks with margin" := on every fixture where the rule binds (helpers.ranking_yardstick) the fp32 top-5 set is kept AND the
+# centred drift (what a ranking sees) is <= half the designed rank-5/6 gap.
+FP8_WHOLE_STACK_RANKS = False        # frozen verdict of "fp8_first_layer" = 0 (both FFN-down forms); a change that flips it must edit this line
+FP8_WHOLE_STACK_SANITY = dict(max_abs=1.2, rho=0.3)     # frozen: finite, bounded, still correlated with the reference (measured <= 0.82 / >= 0.375)
+
+
+def _ranks_with_margin(rows):
+    binding = [r for r in rows if r["y"]["binds"]]
+    return binding, all(r["kept"] and r["stats"]["centred"] <= 0.5 * r["y"]["gap"] for r in binding)
+
+
+@pytest.mark.parametrize("name", _fixtures())
+def test_fp8_default_subset_ranks_wherever_the_reference_arithmetic_does(name):
+    """rr_config.fp8 as shipped (e4m3 QKV / FFN-up in the last two text-encoder layers): on every list where the rule binds the fp32
+    top-5 set is kept with the centred drift inside half the designed gap, and Recall@5/10 equal the fp32 reference's."""
     import rmr_amd
     from helpers import arch_from_cfg, load_fullsize
-    cfg, w, vision, qs = load_fullsize("c5_sep")
+    cfg, w, vision, qs = load_fullsize(name)
     arch = arch_from_cfg(cfg, vision, "fp16")
     arch["fp8"] = 1
     eng = rmr_amd.RerankEngine(arch)
     eng.load_state_dict(w)
-    eng.set_option("fp8_ffn_down", down)
-    kept, got, want = _rank_c5_sep(eng, qs, "fp8/ffn_down_" + ("e4m3" if down else "16bit"))
-    if not (all(kept) and got == want):
-        pytest.xfail(f"fp8 (fp8_ffn_down={down}) loses the fp32 top-5 on c5_sep: sets kept {kept}, Recall@5/10 {got['recall']} vs {want['recall']}")
+    assert eng.get_option("fp8_first_layer") == cfg.layers - 2 and eng.get_option("fp8_qkv") == 1 and eng.get_option("fp8_ffn_down") == 0
+    rows, got, want = _rank_lists(eng, name, qs, "fp8/default_last2")
+    binding, ok = _ranks_with_margin(rows)
+    assert ok
+    if len(binding) == len(rows):
+        assert got == want
+
+
+@pytest.mark.parametrize("down", [0, 1])
+def test_fp8_whole_stack_verdict_is_the_frozen_one(down):
+    """"fp8_first_layer" = 0 (e4m3 in all 24 layers; with and without the e4m3 FFN-down): the ranking verdict over ALL c5 ranking
+    fixtures is the frozen FP8_WHOLE_STACK_RANKS — an equality, so that a change which makes the whole stack rank (or one that breaks
+    a fixture) fails here and has to edit the constant and the documentation — and the drift stays inside frozen sanity bounds."""
+    import rmr_amd
+    from helpers import arch_from_cfg, load_fullsize
+    all_rows = []
+    for name in _fixtures():
+        cfg, w, vision, qs = load_fullsize(name)
+        arch = arch_from_cfg(cfg, vision, "fp16")
+        arch["fp8"] = 1
+        eng = rmr_amd.RerankEngine(arch)
+        eng.load_state_dict(w)
+        eng.set_option("fp8_first_layer", 0)
+        eng.set_option("fp8_ffn_down", down)
+        rows, _, _ = _rank_lists(eng, name, qs, "fp8/whole_stack/ffn_down_" + ("e4m3" if down else "16bit"))
+        all_rows += rows
+        del eng
+        torch.cuda.empty_cache()
+    for r in all_rows:
+        assert r["stats"]["max_abs"] <= FP8_WHOLE_STACK_SANITY["max_abs"] and r["stats"]["rho"] >= FP8_WHOLE_STACK_SANITY["rho"]
+    binding, ok = _ranks_with_margin(all_rows)
+    assert binding, "no fixture binds: the verdict would be vacuous"
+    assert ok == FP8_WHOLE_STACK_RANKS

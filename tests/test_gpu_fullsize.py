@@ -4,7 +4,7 @@ candidate-permutation equivariance, duplicate candidates, and the rank being a d
 import pytest
 import torch
 
-from helpers import O, arch_from_cfg
+from helpers import O, arch_from_cfg, fullsize_bf16_gate, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -49,10 +49,14 @@ def test_production_gemm_equals_simple_gemm_through_the_forward(setup):
     # (an intermittent 1e-3..8e-3 gap here was lost residual terms from compiler-packed f32 code, build.py)
     assert torch.equal(a, b), f"max |dlogit| {(a - b).abs().max().item():.2e}"
     # the split stream carries 19 (bf16 operands) / 22 (fp16) bits of each residual row instead of 24: the logits move by
-    # re-decided 16-bit roundings only.  Both are bf16-operand forwards, each 2.4e-3 - 2.8e-3 from the fp32 golden on c3_full
-    # (profiles/r04_parity_margins.json "c3_full/bf16/split_vs_fp32_stream"); two such results lie at most twice that apart.
-    # (3e-3 until the K walk of every second column block was reversed, which re-decided the roundings of both: 4.1e-3 here.)
-    assert (prod - a).abs().max().item() < 6e-3, f"split vs fp32 residual stream: {(prod - a).abs().max().item():.2e}"
+    # re-decided 16-bit roundings only.  WHAT each stream owes the reference is gated where a reference exists — on c3_full, each
+    # against the fp32 golden (test_gpu_forward.py test_split_residual_stream_costs_no_accuracy; helpers.bf16_gate) — and this
+    # shape has no golden, so the pairwise distance is RECORDED, and bounded only by what that gate implies (VERDICT r4 item 8:
+    # a yardstick, not the value last observed): two bf16-operand forwards that are each within fullsize_bf16_gate("c3_full") =
+    # max(1e-3, 1.5 x the reference's own bf16-autocast drift on that shape) of the same fp32 result lie at most twice that apart.
+    d_pair = (prod - a).abs().max().item()
+    record_margin("c3_shape/bf16/split_vs_fp32_stream_pairwise", bound=2 * fullsize_bf16_gate("c3_full"), max_abs=d_pair)
+    assert d_pair <= 2 * fullsize_bf16_gate("c3_full"), f"split vs fp32 residual stream: {d_pair:.2e}"
     c = _fwd(s)["logits"]
     assert torch.equal(prod, c)                             # and run to run
 

@@ -159,3 +159,34 @@ def test_packed_forward_at_the_bench_size(vision, dt):
         assert d < 5e-4         # here and there (the fp16 forward itself sits 3.2e-4 from fp32 at this size)
     else:
         assert d == 0.0 and torch.equal(got["order"], ref["order"])
+
+
+def test_sharded_slices_and_the_whole_list_agree_within_the_parity_gate():
+    """a pair's roundings depend on how many rows share its launch — below 128 tiles of 256 x 256 (about 11k rows at
+    H = 768) the residual stream between the epilogues is fp32, above it the (hi, lo) pair (rr_gemm_split_ok), and the cut lies
+    between the 13-pair and 25-pair strong-scaling shards of one K = 100 query.  So the logits of a sharded run are NOT bit-equal
+    to the single-GPU run; what must hold is the parity bar itself: on c3_full (K = 100, S = 512, 81 vision tokens) the eight
+    13 / 12-pair slices of SURVEY 8(e) (fp32 stream) and the whole list (split stream) are each within north_star's 1e-3 of the
+    fp32 stock-HF golden in fp16, and the pairwise difference — which two results that close to the same reference bound by the
+    triangle inequality — is recorded (measured ~2e-4), not gated by a looser number of its own."""
+    import rmr_amd
+    cfg, w, vision, qs = load_fullsize("c3_full")
+    q = qs[0]
+    eng = _engine(cfg, vision, w, "fp16")
+    K = q["ids"].shape[0]
+    ids, am, tt = q["ids"].cuda(), q["am"].cuda(), q["tt"].cuda()
+    cls, pat = q["img"][0].cuda(), q["img"][1].cuda()
+    whole = eng.forward_ids(ids, am, tt, 1, K, cls, pat, None)["logits"].cpu().reshape(-1)
+    parts = torch.full((K,), float("nan"))
+    for r in range(8):
+        b, e = rmr_amd.shard_range(K, r, 8)
+        out = eng.forward_ids(ids, am, tt, 1, K, cls, pat, None, pair_range=(b, e), want_loss=False)["logits"].cpu().reshape(-1)
+        parts[b:e] = out[b:e]
+    torch.cuda.synchronize()
+    ref = q["fp32"]
+    d_whole, d_parts = (whole - ref).abs().max().item(), (parts - ref).abs().max().item()
+    d_pair = (whole - parts).abs().max().item()
+    print(f"[c3_full/fp16 sharded 8 x 13/12 pairs] |whole - fp32| {d_whole:.2e}  |slices - fp32| {d_parts:.2e}  |whole - slices| {d_pair:.2e}")
+    record_margin("c3_full/fp16/sharded_8_slices", gate=1e-3, whole_vs_slices=d_pair, **margin_stats(parts, ref))
+    assert torch.isfinite(parts).all()
+    assert d_whole <= 1e-3 and d_parts <= 1e-3        # each against the fp32 golden, north_star's tolerance

@@ -163,7 +163,10 @@ def test_attention_fusion_oracle_matches_golden():
     assert torch.allclose(adj[:, Tq:, :Tq].sum(-1), torch.ones(adj.shape[0], adj.shape[1] - Tq), atol=1e-5)
 
 
-@pytest.mark.parametrize("name,K,gap", [("c3_sep", 100, 0.08), ("c5_sep", 200, 0.12)])
+# (fixture, list length, designed rank-5/6 gap; None = stored with the fixture as `gap_design`: a fraction of the pool's logit spread
+# or the widest gap the pool allows, tests/golden/make_golden.py SEP)
+@pytest.mark.parametrize("name,K,gap", [("c3_sep", 100, 0.08), ("c5_sep", 200, 0.12), ("c5_sep_wide", 200, None), ("c5_sep_g20", 200, None),
+                                        ("c5_sep_g15", 200, None)])
 def test_ranking_fixtures_are_what_they_claim(name, K, gap):
     """The Recall@5 fixtures (tests/golden/make_golden.py run_fullsize_case) without a GPU: per query a list of K distinct pool
     candidates whose fp32 stock-HF logits leave the designed gap between rank 5 and rank 6, the single positive at fp32 rank 5
@@ -179,9 +182,38 @@ def test_ranking_fixtures_are_what_they_claim(name, K, gap):
         ref = z[f"q{qi}.pool_logits"][sel]
         order = O.rank_descending_stable(ref.tolist())
         s = np.sort(ref)[::-1]
-        assert s[4] - s[5] >= gap and abs((s[4] - s[5]) - float(z[f"q{qi}.gap_5_6"])) < 1e-6
+        want_gap = gap if gap is not None else float(z[f"q{qi}.gap_design"])
+        assert s[4] - s[5] >= want_gap - 1e-6 and abs((s[4] - s[5]) - float(z[f"q{qi}.gap_5_6"])) < 1e-6
         p = int(z[f"q{qi}.positive_list_index"])
         assert order.index(p) == (4 if qi == 0 else 5)
         ranked.append(order)
         pos.append([p])
     assert O.recall_precision_at_k(ranked, pos, [5, 10])["recall"] == [0.5, 1.0]
+
+
+# Where the rule of the reduced-precision ranking tests BINDS (tests/helpers.ranking_yardstick: the reference's own bf16-autocast
+# arithmetic keeps the fp32 top-5 of the list with max |autocast - fp32| <= gap / 4), frozen per fixture and query.  The lists of
+# c5_sep / c5_sep_g20 / c5_sep_g15 do NOT bind: the autocast reference's own drift is 0.6 - 0.9 of their gap (it keeps its top-5 there
+# by the draw); c5_sep_wide (the widest gap the same pool allows) and query 1 of c3_sep do.
+RULE_BINDS = {"c3_sep": (False, True), "c5_sep": (False, False), "c5_sep_wide": (True, True), "c5_sep_g20": (False, False),
+              "c5_sep_g15": (False, False)}
+
+
+@pytest.mark.parametrize("name", sorted(RULE_BINDS))
+def test_every_ranking_fixture_carries_the_reference_autocast_yardstick(name):
+    """each ranking fixture stores what the reference's own arithmetic (bf16 autocast,
+    configs/Rerank/OKVQA/Encoder/monoPreFLMR-B_pointwise.jsonnet:186,233) does on its pool — no NaN placeholder — and the lists on
+    which the rule binds are the frozen ones."""
+    import numpy as np
+    import torch
+    from helpers import margin_stats, top5_set
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False)
+    binds = []
+    for qi in range(int(z["nq"])):
+        sel = z[f"q{qi}.selected"].astype(np.int64)
+        ref, ac = torch.from_numpy(z[f"q{qi}.pool_logits"])[sel], torch.from_numpy(z[f"q{qi}.pool_logits_autocast"])[sel]
+        assert torch.isfinite(ac).all() and not torch.equal(ac, ref)
+        st, gap = margin_stats(ac, ref), float(z[f"q{qi}.gap_5_6"])
+        assert top5_set(ac) == top5_set(ref)              # the autocast reference ranks every committed list (by margin or by the draw)
+        binds.append(bool(st["max_abs"] <= gap / 4))
+    assert tuple(binds) == RULE_BINDS[name]

@@ -25,13 +25,23 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--no-timeline", action="store_true")
 ap.add_argument("--shapes", default="qkv,attn_out,ffn1,ffn2")
 ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT")
+ap.add_argument("--lib", default=None, help="another build of the library (tools/build_variant.py), e.g. tools/bin/librerank_epidiag1.so")
+ap.add_argument("--grid", type=int, default=256, help="run the persistent kernels on this many CUs only (rr_set_tuning gemm_grid_cus; a multiple of 8): "
+                "what an epilogue costs when fewer CUs share the memory system")
 ap.add_argument("--stagger", type=int, default=0, help="rr_set_gemm_stagger: 50..55 = tile-order group of 2..64 row panels, 56 = row-major, 59 = no serpentine K walk")
 a = ap.parse_args()
+if a.lib:
+    import ctypes
+    _lib.LIB_PATH = os.path.abspath(a.lib)
+    _probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib._SIGS = {k: v for k, v in _lib._SIGS.items() if hasattr(_probe, k)}
 lib = _lib.load()
 st = torch.cuda.current_stream().cuda_stream
 M = a.pairs * 512
 assert lib.rr_set_op_dtype(1) == 0
 assert lib.rr_set_gemm_stagger(a.stagger) == 0
+if a.grid != 256:
+    assert a.grid % 8 == 0 and lib.rr_set_tuning(b"gemm_grid_cus", a.grid) == 0
 for kv in a.tuning:
     k_, v_ = kv.split("=")
     assert lib.rr_set_tuning(k_.encode(), int(v_)) == 0, kv
@@ -90,7 +100,7 @@ for name in a.shapes.split(","):
     print(line, flush=True)
     if a.no_timeline:
         continue
-    grid = 256
+    grid = a.grid
     buf = torch.zeros(grid * 8 + grid * 128 + grid * 128 + grid * 64, dtype=torch.int64, device="cuda")
     lib.rr_set_gemm_variant(15)
     lib.rr_set_gemm_stamps(buf.data_ptr())
@@ -120,4 +130,5 @@ for name in a.shapes.split(","):
     print(f"   workgroups inside their epilogue at a time: mean {inside.mean():.2f}  min {inside.min():.2f}  max {inside.max():.2f}  "
           f"(lockstep: min near 0, max near 1; spread: both near the mean)")
 lib.rr_set_gemm_variant(-1)
+lib.rr_set_tuning(b"gemm_grid_cus", 0)
 lib.rr_set_op_dtype(0)

@@ -49,6 +49,18 @@ def load(d, counter, key=klass):
     return tot, n
 
 
+def load_by_shape(d, counter, pat):
+    """Per-dispatch values of the kernel whose short name starts with `pat`, in dispatch order, split by the PARITY of the occurrence
+    (the two residual GEMMs of a layer — attention-out N 768 / K 768 and FFN-down N 768 / K 3072 — are the same kernel and alternate)."""
+    rows = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and short(r["Kernel_Name"]).startswith(pat):
+                rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"])))
+    rows.sort()
+    return [v for _, v in rows[0::2]], [v for _, v in rows[1::2]]
+
+
 fd, wd = sys.argv[1], sys.argv[2]
 f, nf = load(fd, "FETCH_SIZE")
 w, nw = load(wd, "WRITE_SIZE")
@@ -64,6 +76,20 @@ wk, nwk = load(wd, "WRITE_SIZE", short)
 per_kernel = {k: {"launches": nfk[k], "read_gb_per_launch": round(2.0 * fk[k] * 1024.0 / nfk[k] / 1e9, 4),
                   "write_gb_per_launch": round(wk.get(k, 0.0) * 1024.0 / max(1, nwk.get(k, 0)) / 1e9, 4)}
               for k in sorted(fk, key=lambda k: -fk[k]) if 2.0 * fk[k] * 1024.0 > 1e8}
-print(json.dumps({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py (c3, 800 pairs, "
+# the split-residual kernel by SHAPE.  Which parity is FFN-down is read off the data (it reads the 2.5 GB FFN
+# intermediate, attention-out the 0.63 GB attention output); the same parity then labels the WRITE_SIZE pass (same dispatch order).
+RESID = "gemm_kernel_hp<4, 1, 3"
+fe, fo = load_by_shape(fd, "FETCH_SIZE", RESID)
+we, wo = load_by_shape(wd, "WRITE_SIZE", RESID)
+per_shape = {}
+if fe and fo:
+    mean = lambda v: sum(v) / max(1, len(v))
+    even_is_down = mean(fe) > mean(fo)
+    for label, fr, wr_, alg_r, alg_w in (("FFN-down (N 768, K 3072)", fe if even_is_down else fo, we if even_is_down else wo, 3.78, 1.28),
+                                         ("attention-out (N 768, K 768)", fo if even_is_down else fe, wo if even_is_down else we, 1.89, 1.28)):
+        per_shape[RESID + ", 0, false> " + label] = {"launches": len(fr), "read_gb_per_launch": round(2.0 * mean(fr) * 1024.0 / 1e9, 4),
+                                                     "write_gb_per_launch": round(mean(wr_) * 1024.0 / 1e9, 4),
+                                                     "algorithmic_read_gb": alg_r, "algorithmic_write_gb": alg_w}
+print(json.dumps({"per_shape": per_shape, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py (c3, 800 pairs, "
                           "1 warm-up + 1 step); FETCH_SIZE doubled per the gfx950 correction",
                   "per_kernel_class": out, "per_kernel": per_kernel}, indent=1))
