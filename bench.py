@@ -163,6 +163,29 @@ def archived_pmc():
                 out["vendor_gemm_source"] = os.path.relpath(files_v[-1], ROOT)
         except Exception:
             pass
+    # the framework's own fused attention (torch SDPA, whichever backend the image's PyTorch-ROCm offers) at the path's shape beside
+    # this repo's attention launch, one process, same operands (tools/bench_vendor_attention.py): yardstick only, never on the product path
+    files_a = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_vendor_attention.json")))
+    if files_a:
+        try:
+            d = json.load(open(files_a[-1]))
+            y = {}
+            for dt in ("fp16", "bf16"):
+                rs = [r for r in d["results"] if r["dtype"] == dt and "ms_min" in r]
+                ours = [r for r in rs if r["impl"].startswith("ours")]
+                biased = [r for r in rs if r["impl"].startswith("sdpa") and r.get("mask", "").startswith("key bias") and "math" not in r["impl"]]
+                plain = [r for r in rs if r["impl"].startswith("sdpa") and r.get("mask") == "no mask" and "math" not in r["impl"]]
+                if ours and biased and plain:
+                    b, p = min(biased, key=lambda r: r["ms_min"]), min(plain, key=lambda r: r["ms_min"])
+                    y[dt] = {"this_kernel_with_key_bias_ms": ours[0]["ms_min"], "sdpa_best_with_key_bias_ms": b["ms_min"],
+                             "sdpa_best_with_key_bias_backend": b["impl"], "sdpa_best_without_mask_ms": p["ms_min"],
+                             "sdpa_best_without_mask_backend": p["impl"]}
+            if y:
+                out["vendor_attention_yardstick"] = dict(y, shape=d.get("shape"), torch=d.get("torch"),
+                                                         note="stand-alone launches back to back (higher clock than inside the step)")
+                out["vendor_attention_source"] = os.path.relpath(files_a[-1], ROOT)
+        except Exception:
+            pass
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")) if "_c5" not in os.path.basename(f))
     if files:
         try:

@@ -132,7 +132,7 @@ int rr_set_gemm_stamps(void* device_buf);
 int rr_set_attn_stamps(void* device_buf);   /* diagnostic timeline of the attention kernel: 4 x 8 uint64 per workgroup, or NULL */
 int rr_set_attn_redo_stats(void* device_buf);   /* diagnostic: DEVICE 2 x uint64 — the redo launches of the fixed-reference attention add (workgroups flagged for the online recompute, workgroups looked at) — or NULL */
 int rr_set_gemm_stagger(int unit);   /* diagnostic codes of the 16-bit GEMM kernels, 0 = none: 1..49 start skew of the first dispatch wave in
-                                       s_sleep(127) units; 50..55 tile-order groups of 2..64 row panels, 56 row-major; 59 = the persistent ring
+                                       s_sleep(127) units; 50..55 tile-order groups of 2..64 row panels, 56 row-major, 57 = round 4's rule (groups of 8 also for N <= 1024); 59 = the persistent ring
                                        WITHOUT its serpentine K walk (every second block of 1 024 output columns accumulates its K-tiles from the
                                        last to the first: gemm_bf16.hip k_walk_reversed; with 59 the ring no longer agrees to the bit with the
                                        simple kernel, which keeps the rule); 61..64 timeline builds only */

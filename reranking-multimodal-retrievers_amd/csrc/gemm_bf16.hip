@@ -858,8 +858,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
   // (profiles/r03_q_tile_order_ab.txt).
   const bool mrev = stagger_unit >= 1000;                   // this launch walks its tile lists from the end (rr_m_direction_next)
   if (mrev) stagger_unit -= 1000;
+  // N <= 1024 (at most four column slices: the N = 768 residual GEMMs): plain row-major as well — the whole weight fits L2 anyway, and
+  // the column tiles of a row panel then run side by side in ONE round instead of straddling two (attention-out reads 2.46 -> 2.13 GB
+  // per launch beyond L2, profiles/r05_i_attn_out_tile_order.log; launch time within +-1 % for groups of 1 / 2 / 4 / 8,
+  // profiles/r05_j_resid_tile_order.log: those re-reads are served by the memory-side cache and were never what the launch waits for).
   const int GROUP = stagger_unit >= 50 && stagger_unit <= 55 ? (2 << (stagger_unit - 50))      // A/B: 2..64
-                    : (stagger_unit == 56 || Kd > 1024) ? 1 : 8;
+                    : (stagger_unit == 56 || Kd > 1024 || (tiles_n <= 4 && stagger_unit != 57)) ? 1 : 8;      // 57: the old rule (A/B)
   // De-synchronise the XCDs (rr_set_tuning "gemm_desync"; stagger_unit = 100 + u).  All workgroups of a persistent launch start
   // together and every tile costs the same, so the 256 CUs run their main loops (HBM nearly idle) and then their epilogues
   // (HBM saturated) in LOCKSTEP: tools/gemm_epilogue_timeline.py shows every workgroup inside its epilogue at the same
@@ -1189,6 +1193,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
 #undef RR_MARK
 #undef RR_ACC
   wait_vmcnt<0>();   // nothing is in flight any more (every issued half-tile was waited for); explicit before LDS reuse
+  // One K-tile only (K = 64): the loop above has no counted wait at all (wait_half returns for half-tiles beyond the last), so its
+  // barriers did not order the OTHER waves' parameter-block pieces — requested behind the previous tile's epilogue — before this
+  // tile's epilogue reads them: a later tile of a workgroup could add the previous column tile's bias (found in round 5 by
+  // test_ring_kernels_ragged_multi_tile[8453-2304-64-14], intermittent).  With two or more K-tiles the first counted wait + barrier
+  // of the loop covers the block, which is older than every ring refill of its tile.  Uniform branch, never taken on the path (K >= 128).
+  if (nk == 1) __builtin_amdgcn_s_barrier();
   if (first_tile) stamp(stamps, 2);
   EP_ADD(0)
   // DIAG: wall-clock (100 MHz s_memrealtime) of the start and end of the first 32 epilogues of every workgroup, to see
@@ -1649,7 +1659,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
+                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 57) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
   }
 #define RR_GEMM_CASE(E)                                                                                       \
   case E: {                                                                                                   \
@@ -1674,7 +1684,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
       if (e != hipSuccess) return e;                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, A, lda, W, ldw, bias, resid, ldr, C, ldc, M, N, Kd,  \
-                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 56) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
+                       tiles_n, nwg, stamps, ln, (((g_stagger >= 50 && g_stagger <= 57) || g_stagger == 59) ? g_stagger : desync) + 1000 * mrev);       \
     return hipGetLastError();                                                                                 \
   }
   switch (split) {

