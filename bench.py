@@ -163,6 +163,24 @@ def archived_pmc():
                 out["vendor_gemm_source"] = os.path.relpath(files_v[-1], ROOT)
         except Exception:
             pass
+    # what the matrix core SUSTAINS on this chip under its power cap (tools/mfma_shape_probe.hip: every CU, two waves per SIMD, random
+    # fp16 operands; with the GEMM main loop's 12 ds_read_b128 per 32 MFMAs beside them): the physical ceiling of an LDS-fed tile loop,
+    # below the 2.5 PFLOP/s nominal peak that roofline.frac is priced against
+    files_m = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_shape_probe.log")))
+    if files_m:
+        try:
+            import re
+            best = {}
+            for line in open(files_m[-1]):
+                mo = re.match(r"(\S+ f16)(, registers only| \+ 12 ds_read_b128)\s+rep \d+:\s+[\d.]+ ms\s+([\d.]+) TFLOP/s", line)
+                if mo:
+                    k = mo.group(1).split()[0] + ("_registers_only" if "registers" in mo.group(2) else "_with_lds_fragment_reads")
+                    best[k] = max(best.get(k, 0.0), float(mo.group(3)))
+            if best:
+                out["sustained_mfma_probe_tflops"] = best
+                out["sustained_mfma_probe_source"] = os.path.relpath(files_m[-1], ROOT)
+        except Exception:
+            pass
     # the framework's own fused attention (torch SDPA, whichever backend the image's PyTorch-ROCm offers) at the path's shape beside
     # this repo's attention launch, one process, same operands (tools/bench_vendor_attention.py): yardstick only, never on the product path
     files_a = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_vendor_attention.json")))
@@ -507,6 +525,12 @@ def main():
                                "avg_launch_gflop": g["flops"] / max(1, g["launches"]) / 1e9,
                                "note": "live: per-launch HIP events on the work stream INSIDE the timed region, rank 0 "
                                        "(they cost ~1 % of the step; --no-profile removes them)"}
+            sus = (apm.get("sustained_mfma_probe_tflops") or {}).get("16x16x32_with_lds_fragment_reads")
+            if sus:
+                res["roofline"]["frac_of_sustained_mfma_probe"] = ach / sus
+                res["roofline"]["sustained_mfma_probe_note"] = (f"{sus:.0f} TFLOP/s = what v_mfma_f32_16x16x32_f16 sustains on this chip under its power cap "
+                                                                "with the main loop's LDS fragment reads beside it and nothing else (archived probe, "
+                                                                "archived_pmc.sustained_mfma_probe_source); frac stays priced against the 2.5 PFLOP/s nominal peak")
             g8 = prof.get("gemm_fp8")
             if g8 and g8["launches"]:
                 a8 = g8["flops"] / (g8["ms"] * 1e-3) / 1e12

@@ -1,4 +1,4 @@
-"""Render DESIGN.md from docs/DESIGN.in.md: every measured figure of the document is an expression
+"""Render DESIGN.md / README.md from docs/DESIGN.in.md / docs/README.in.md: every measured figure of a document is an expression
 
     {{profiles/<file>.json "<key>" "<key>" ...|<python format spec>}}        e.g.  {{profiles/r05_h_c3_bench.json.log "value"|.0f}}
 
@@ -7,7 +7,7 @@ tests/test_docs_cpu.py checks (`<number> [`profiles/<file>.json` "<key>" ...]`).
 tables: the row or the caption carries the citation).  A `.json.log` file is a bench log whose last line starting with `{` is the
 record.  Nothing is scaled: the document quotes the records in the records' own units.
 
-    python tools/render_docs.py            # writes DESIGN.md; fails on a missing file / key
+    python tools/render_docs.py            # writes DESIGN.md and README.md; fails on a missing file / key
 """
 import json
 import os
@@ -41,10 +41,11 @@ def render(text):
 
 
 if __name__ == "__main__":
-    src = os.path.join(ROOT, "docs", "DESIGN.in.md")
-    out = render(open(src, encoding="utf-8").read())
-    left = re.findall(r"\{\{[^}]*\}\}", out)
-    if left:
-        sys.exit(f"unrendered expressions: {left[:5]}")
-    open(os.path.join(ROOT, "DESIGN.md"), "w", encoding="utf-8").write(out)
-    print("DESIGN.md:", out.count("\n") + 1, "lines,", len(EXPR.findall(open(src, encoding='utf-8').read())), "figures from records")
+    for name in ("DESIGN", "README"):                      # docs/<name>.in.md -> <name>.md
+        src = os.path.join(ROOT, "docs", name + ".in.md")
+        out = render(open(src, encoding="utf-8").read())
+        left = re.findall(r"\{\{[^}]*\}\}", out)
+        if left:
+            sys.exit(f"{name}: unrendered expressions: {left[:5]}")
+        open(os.path.join(ROOT, name + ".md"), "w", encoding="utf-8").write(out)
+        print(name + ".md:", out.count("\n") + 1, "lines,", len(EXPR.findall(open(src, encoding='utf-8').read())), "figures from records")
