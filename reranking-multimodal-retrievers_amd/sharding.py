@@ -57,6 +57,7 @@ class _GatherPlan:
         self.blk = heads * self.per + 1                                  # + the status word
         self.host = None
         self.send = torch.zeros(self.blk, dtype=dtype, device=device)
+        self.sent_status = STATUS_OK                                     # what send[-1] holds (rewritten only when it changes: no launch in the steady state)
         self.recv = torch.empty(world * self.blk, dtype=dtype, device=device)
         # compaction map: full[h][i] = recv[rank(i), h, i - begin(rank)], then the `world` status words — one index_select, no cat
         idx = torch.empty(heads, n_pairs, dtype=torch.int64)
@@ -105,7 +106,9 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
     p.send[:n_loc].copy_(local.reshape(-1))
     if local2 is not None:
         p.send[p.per: p.per + n_loc].copy_(local2.reshape(-1))
-    p.send[p.blk - 1] = float(status)
+    if status != p.sent_status:
+        p.send[p.blk - 1] = float(status)
+        p.sent_status = status
     if p.send.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal on one GPU (bench.py --rehearse-one-gpu): gloo has no device all-gather, stage through the host
         if p.host is None:
