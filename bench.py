@@ -507,8 +507,8 @@ def main():
         if args.fp8:
             fl, fq, fd = (eng.get_option(k) for k in ("fp8_first_layer", "fp8_qkv", "fp8_ffn_down"))
             res["config"]["fp8_layers"] = (f"e4m3 QKV / FFN-up operands in text-encoder layers {fl}..{arch['layers'] - 1} of {arch['layers']} "
-                                           f"(handle options fp8_first_layer={fl}, fp8_qkv={fq}, fp8_ffn_down={fd}); the shipped default is the last two "
-                                           "layers, the largest subset that ranks with margin; --tuning fp8_first_layer=0 = the whole stack")
+                                           f"(handle options fp8_first_layer={fl}, fp8_qkv={fq}, fp8_ffn_down={fd}); the shipped default is the last "
+                                           "layer, the largest subset that ranks with a robust margin; --tuning fp8_first_layer=0 = the whole stack")
             res["ranking"] = archived_fp8_ranking(fl, fq, fd)
         if prof is not None:
             g = prof["gemm"]

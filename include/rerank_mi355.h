@@ -197,14 +197,15 @@ int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
  *                                                     pair only (all the classifiers read, utils.py:105-108); 0: every row
  *   "fp8_ffn_down"   0 | 1                  0         rr_config.fp8 only: FFN-down on the e4m3 ring too (GELU output as e4m3 under a
  *                                                     static scale of 8); 0: FFN-down keeps 16-bit operands
- *   "fp8_first_layer" 0 .. layers           layers-2  rr_config.fp8 only: text-encoder layers with an index below this value keep
+ *   "fp8_first_layer" 0 .. layers           layers-1  rr_config.fp8 only: text-encoder layers with an index below this value keep
  *                                                     16-bit operands (the folded-LayerNorm dataflow); layers from it on run the
  *                                                     e4m3 configuration.  `layers` (or more) = no e4m3 GEMM at all; 0 = every
  *                                                     layer (the whole-stack form: 1.13x the 16-bit line on bert-large, and
  *                                                     MEASURED not to keep the fp32 top-5 on the ranking fixtures — opt in only
  *                                                     with a checkpoint you have validated).  A perturbation injected early is
  *                                                     amplified by every later layer, so e4m3 goes into the LAST layers first;
- *                                                     the default is the largest subset that ranks with margin (DESIGN.md "fp8")
+ *                                                     the default (the last layer only) is the largest subset that ranks with a margin that survives
+ *                                                     a re-draw of unrelated roundings (DESIGN.md "fp8")
  *   "fp8_qkv"        0 | 1                  1         rr_config.fp8 only: 0 = of an e4m3 layer only the FFN takes e4m3 operands,
  *                                                     its QKV projection keeps 16-bit ones
  *   "attn_fixed_ref" 0 | 1 | 2 | 3          3         softmax schedule of large attention grids: 0 online only, 1 fixed reference

@@ -183,6 +183,8 @@ __device__ __forceinline__ f32x4 fold_apply(f32x4 acc, float2 st, float4 cs, flo
   return f32x4{fmaf(acc[0], st.y, fmaf(ms, cs.x, bv.x)), fmaf(acc[1], st.y, fmaf(ms, cs.y, bv.y)),
                fmaf(acc[2], st.y, fmaf(ms, cs.z, bv.z)), fmaf(acc[3], st.y, fmaf(ms, cs.w, bv.w))};
 }
+// (Round 5: the same two multiply-adds as v_pk_fma_f32 on column pairs in the persistent ring's epilogue — bit-identical, fenced
+// against the packed-f32 rule — bought nothing: 85.83 vs 85.85 ms per step, profiles/r05_q_pk_fold_ab.txt.  Removed.)
 __device__ __forceinline__ float4 ln_apply(float4 x, const LnResid& ln, int gm, int gn) {
   if (!ln.stats) return x;
   float2 st = ln.stats[gm];

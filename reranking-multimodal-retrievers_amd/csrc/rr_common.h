@@ -135,14 +135,20 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// erf-GELU, gelu(x) = max(x, 0) - z Phi(-z) with z = min(|x|, 5.7) and log2 Phi(-z) a degree-7 polynomial in z (a weighted
-// Chebyshev fit on [0, 5.7], the weight being z Phi(-z) itself): ten plain VALU operations and ONE transcendental (the
-// exp2) instead of eleven and two (exp2 + rcp) for the Abramowitz-Stegun 7.1.26 form used before — the GELU runs exposed
-// in the FFN-up epilogue, 128 values per lane and tile.  |gelu - exact| <= 4.8e-7 over [-12, 12] evaluated in fp32
-// (2.1e-7 before), relative error <= 3.4e-5 wherever |gelu| >= 1e-3: three orders below the 16-bit rounding of the output.
+// erf-GELU, gelu(x) = max(x, 0) - z Phi(-z) with z = min(|x|, 5.7) and log2 Phi(-z) a polynomial in z: plain VALU operations
+// and ONE transcendental (the exp2) instead of eleven and two (exp2 + rcp) for the Abramowitz-Stegun 7.1.26 form of round 1 — the
+// GELU runs exposed in the FFN-up epilogue, 128 values per lane and tile, vector-issue-bound.
+// RR_GELU_DEGREE 5 (round 5): a minimax fit of the ABSOLUTE error of z 2^p(z) on [0, 5.7] (Lawson reweighting:
+// tools/study/fit_gelu_tail.py): |gelu - exact| <= 6.4e-7 over [-12, 12] evaluated in fp32 with fused multiply-adds, relative error <= 2.8e-4
+// wherever |gelu| >= 1e-3 — two FMAs per value fewer than the degree-7 fit of rounds 2-4 (4.8e-7 / 3.4e-5; RR_GELU_DEGREE 7 keeps
+// it for A/B runs), still two to three orders below the 16-bit rounding of the output (fp16: 4.9e-4 relative).
 // Beyond |x| = 5.7 the neglected term is below 6e-8.
+#ifndef RR_GELU_DEGREE
+#define RR_GELU_DEGREE 5
+#endif
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fminf(fabsf(x), 5.7f);
+#if RR_GELU_DEGREE == 7
   float p = -1.403277905e-06f;
   p = fmaf(p, z, 5.490869060e-05f);
   p = fmaf(p, z, -8.929630618e-04f);
@@ -151,6 +157,14 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   p = fmaf(p, z, -4.584285712e-01f);
   p = fmaf(p, z, -1.151314700e+00f);
   p = fmaf(p, z, -9.999805559e-01f);
+#else
+  float p = -4.733084352e-04f;
+  p = fmaf(p, z, 7.084545679e-03f);
+  p = fmaf(p, z, -5.182733759e-02f);
+  p = fmaf(p, z, -4.599924982e-01f);
+  p = fmaf(p, z, -1.150787830e+00f);
+  p = fmaf(p, z, -1.000037670e+00f);
+#endif
   return fmaf(-z, __builtin_amdgcn_exp2f(p), __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()));   // med3(x, 0, +inf) = max(x, 0)
 }
 
@@ -165,6 +179,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
   const f32x2 z = {fminf(fabsf(x.x), 5.7f), fminf(fabsf(x.y), 5.7f)};
+#if RR_GELU_DEGREE == 7
   f32x2 p = {-1.403277905e-06f, -1.403277905e-06f};
   p = __builtin_elementwise_fma(p, z, f32x2{5.490869060e-05f, 5.490869060e-05f});
   p = __builtin_elementwise_fma(p, z, f32x2{-8.929630618e-04f, -8.929630618e-04f});
@@ -173,6 +188,14 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
   p = __builtin_elementwise_fma(p, z, f32x2{-4.584285712e-01f, -4.584285712e-01f});
   p = __builtin_elementwise_fma(p, z, f32x2{-1.151314700e+00f, -1.151314700e+00f});
   p = __builtin_elementwise_fma(p, z, f32x2{-9.999805559e-01f, -9.999805559e-01f});
+#else
+  f32x2 p = {-4.733084352e-04f, -4.733084352e-04f};
+  p = __builtin_elementwise_fma(p, z, f32x2{7.084545679e-03f, 7.084545679e-03f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-5.182733759e-02f, -5.182733759e-02f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-4.599924982e-01f, -4.599924982e-01f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-1.150787830e+00f, -1.150787830e+00f});
+  p = __builtin_elementwise_fma(p, z, f32x2{-1.000037670e+00f, -1.000037670e+00f});
+#endif
   const f32x2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
   const f32x2 m = {__builtin_amdgcn_fmed3f(x.x, 0.0f, __builtin_huge_valf()), __builtin_amdgcn_fmed3f(x.y, 0.0f, __builtin_huge_valf())};
   return __builtin_elementwise_fma(-z, e, m);
