@@ -18,8 +18,9 @@ all-gather.  Every rank's block therefore ends in one status word (0 ok / 1 rang
 still takes part in the exchange (zero logits, its status word set) and every rank raises after it: the failing rank its own
 exception, the others `ShardPeerError` (an OverflowError when the peer's was one) naming the ranks.  Reading the status words
 is one host read of `world` floats per batch; a loop that must not synchronise per batch passes `defer_status=True`: the words
-are copied to pinned memory behind the collective and looked at when the NEXT batch begins (before any collective of that
-batch, so still on every rank together) or in `check_deferred_status()`, which such a loop calls before it uses its results.
+are folded into a device-side running maximum (no allocation, no host read) and NOBODY raises — a rank whose encoder failed keeps
+taking part with zero logits and its status word set — until `check_deferred_status()`, which such a loop calls before it uses its
+results (and which the next non-deferred call runs first): there every rank reads the same maximum and raises together.
 """
 from __future__ import annotations
 
@@ -68,6 +69,7 @@ class _GatherPlan:
         status = torch.arange(world, dtype=torch.int64) * self.blk + (self.blk - 1)
         self.index = torch.cat([idx.reshape(-1), status]).to(device)
         self.full = torch.empty(heads * n_pairs + world, dtype=dtype, device=device)
+        self.status_accum = torch.zeros(world, dtype=dtype, device=device)   # deferred mode: running maximum of the status words
         self.status_host = torch.empty(world, dtype=dtype, device="cpu")
         if torch.device(device).type == "cuda":
             self.status_host = self.status_host.pin_memory()
@@ -94,11 +96,12 @@ def _plan(device, dtype, world, n_pairs, heads, group=None) -> _GatherPlan:
 
 
 def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optional[torch.Tensor] = None, status: int = STATUS_OK,
-                  want_status: bool = False):
+                  want_status: bool = False, defer_status: bool = False):
     """All-gather the ragged per-rank logit slices (and, for the two-head variant, the second head's) into the full
     [n_pairs] vector(s) with ONE collective.  Returns (full, full2 | None) — and, with `want_status`, the `world` status
     words every rank sent (a device tensor of the logits' dtype) as a third element; the tensors are views of buffers that the
-    next call with the same shape overwrites."""
+    next call with the same shape overwrites.  `defer_status`: fold the status words into the plan's running maximum for
+    check_deferred_status() instead."""
     world = dist.get_world_size(group)
     heads = 1 if local2 is None else 2
     p = _plan(local.device, local.dtype, world, n_pairs, heads, group)
@@ -120,33 +123,34 @@ def gather_logits(local: torch.Tensor, n_pairs: int, group=None, local2: Optiona
         dist.all_gather_into_tensor(p.recv, p.send, group=group)
     torch.index_select(p.recv, 0, p.index, out=p.full)
     full1, full2 = p.full[:n_pairs], (p.full[n_pairs:2 * n_pairs] if heads == 2 else None)
+    if defer_status:
+        torch.maximum(p.status_accum, p.full[heads * n_pairs:], out=p.status_accum)
+        _PENDING[id(p)] = (p, dist.get_rank(group))
     return (full1, full2, p.full[heads * n_pairs:]) if want_status else (full1, full2)
 
 
-_DEFERRED = []       # (pinned host copy of a batch's status words, event | None, rank)
-
-
-def _defer_status(st: torch.Tensor, rank: int):
-    host = torch.empty(st.numel(), dtype=st.dtype, device="cpu")
-    ev = None
-    if st.is_cuda:
-        host = host.pin_memory()
-        host.copy_(st, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-    else:
-        host.copy_(st)
-    _DEFERRED.append((host, ev, rank))
+_PENDING: Dict[int, tuple] = {}      # plans whose running status maximum has not been looked at: id -> (plan, rank)
+_OWN_DEFERRED: list = []             # this rank's own encoder exceptions of deferred batches (the first one is re-raised)
 
 
 def check_deferred_status():
-    """Raise what the peers of earlier `defer_status` batches reported (every rank holds the same words, so every rank raises
-    here together, or none does).  Waits only for the copies of those batches."""
-    while _DEFERRED:
-        host, ev, rank = _DEFERRED.pop(0)
-        if ev is not None:
-            ev.synchronize()
-        _raise_collectively(host.tolist(), rank, None)
+    """Look at what the `defer_status` batches since the last check reported: one host read per plan in use.  Every rank holds the
+    same maxima, so every rank raises here together (the rank whose encoder failed its own first exception, its peers
+    ShardPeerError) or none does.  The results of the batches since the failure are to be discarded by the caller."""
+    own = _OWN_DEFERRED[0] if _OWN_DEFERRED else None
+    failed = None
+    for p, rank in list(_PENDING.values()):
+        p.status_host.copy_(p.status_accum)               # synchronises with the stream the gathers ran on
+        words = p.status_host.tolist()
+        p.status_accum.zero_()
+        if failed is None and any(int(w) != STATUS_OK for w in words):
+            failed = (words, rank)
+    _PENDING.clear()
+    _OWN_DEFERRED.clear()
+    if failed is not None:
+        _raise_collectively(failed[0], failed[1], own)
+    elif own is not None:
+        raise own
 
 
 def _raise_collectively(status_words, rank: int, own: Optional[BaseException]):
@@ -178,7 +182,8 @@ class ShardedReranker:
 
     def __call__(self, n_pairs: int):
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
-        check_deferred_status()             # what the previous batch's peers reported, before this batch's collective
+        if not self.defer_status and (_PENDING or _OWN_DEFERRED):
+            check_deferred_status()         # earlier deferred batches are settled before a batch that reports immediately
         b, e = shard_range(n_pairs, rank, world)
         own, status = None, STATUS_OK
         try:
@@ -189,9 +194,10 @@ class ShardedReranker:
             own, status = ex, (STATUS_RANGE if isinstance(ex, OverflowError) else STATUS_ERROR)
             l1 = self.empty(e - b)
             l2 = self.empty(e - b) if self.two_heads else None
-        full1, full2, st = gather_logits(l1, n_pairs, self.group, l2, status=status, want_status=True)
-        if self.defer_status and own is None:
-            _defer_status(st, rank)
+        full1, full2, st = gather_logits(l1, n_pairs, self.group, l2, status=status, want_status=True, defer_status=self.defer_status)
+        if self.defer_status:
+            if own is not None:
+                _OWN_DEFERRED.append(own)                 # raised by check_deferred_status(), together with the peers
         else:
             _raise_collectively(st.tolist(), rank, own)   # one host read of `world` floats per batch
         return self.head(full1, full2)
