@@ -31,7 +31,9 @@
 
 // Diagnostic builds of the split residual epilogue (RR_HIPCC_EXTRA=-DRR_EPI_DIAG=n, never in a product build): bit 0 = its stores
 // happen only for a value that never occurs, bit 1 = its residual loads are replaced by register constants, bit 2 = no LayerNorm
-// statistics (no cross-lane sums, no partial store) — what each part costs the launch (profiles/r05_e_*).
+// statistics (no cross-lane sums, no partial store) — what each part costs the launch (profiles/r05_e_*); bit 3 = the `lo` half is
+// loaded and stored for every second ROW of a pass only (whole cache lines skipped) (WRONG results: what a residual stream of 3 instead of 4 bytes per element
+// would buy, profiles/r05_r_*).
 #ifndef RR_EPI_DIAG
 #define RR_EPI_DIAG 0
 #endif
@@ -1351,7 +1353,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
             rl[u] = make_uint4(0x10001000u + tid, 0x10001000u, 0x10001000u, 0x10001000u);
           } else if constexpr ((SPLIT & 1) != 0) {
             rh[u] = ok ? load_stream_u4(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
-            rl[u] = ok ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr ((RR_EPI_DIAG & 8) != 0) rl[u] = (ok && !(u & 1)) ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            else rl[u] = ok ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
           } else {
             ra[u] = ok ? load_stream_f4(resid + (size_t)gm * ldr + gcol8) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[u] = ok ? load_stream_f4(resid + (size_t)gm * ldr + gcol8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1465,7 +1468,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
                   lo[j] = pack2<1>(f[2 * j] - hb.x, f[2 * j + 1] - hb.y);
                 }
               }
-              store_stream(ln.lo_out + (size_t)gm * ln.ld16 + gcol, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+              if (!((RR_EPI_DIAG & 8) != 0 && (u & 1)))
+                store_stream(ln.lo_out + (size_t)gm * ln.ld16 + gcol, make_uint4(lo[0], lo[1], lo[2], lo[3]));
             } else {
               float* cp = (float*)Cv + (size_t)gm * ldc + gcol;
               store_stream(cp, make_float4(f[0], f[1], f[2], f[3]));
