@@ -381,8 +381,9 @@ def test_bert_large_shape_text_only():
     ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=21, regime="realistic")
     with torch.no_grad():
         ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K)
-    # measured (profiles/r04_parity_margins.json): fp16 9.2e-4 (round 3: 9.9e-4; |logit| up to 1.23, i.e. 8e-4 relative after 25 layers — the one
-    # case a hair under 1e-3, hence a gate of 1.3e-3), bf16 5.5e-3 (gate 6.7e-3)
+    # measured: fp16 1.1e-03 [`profiles/r05_parity_margins.json` "bert_large_shape_K4_S128/fp16" "max_abs"] (|logit| up to 1.23, i.e. 8e-4 relative
+    # after 25 layers — the one case a hair under 1e-3, hence a gate of 1.3e-3), bf16 3.3e-03 [`profiles/r05_parity_margins.json` "bert_large_shape_K4_S128/bf16" "max_abs"]
+    # (gate 6.7e-3)
     for dtype, tol in (("fp16", 1.3e-3), ("bf16", 6.7e-3)):
         eng = rmr_amd.RerankEngine(arch_from_cfg(cfg, False, dtype))
         eng.load_state_dict(w)
