@@ -84,6 +84,9 @@ def parse_args(argv=None):
                     help="packed execution (RerankEngine.forward_ids_packed / rr_forward_packed): the pairs grouped by length in steps "
                          "of --granule rows, every GEMM of a layer ONE launch over the rows that exist; pairs/s still counts padded pairs")
     ap.add_argument("--granule", type=int, default=16, help="row-length step of --packed")
+    ap.add_argument("--segment-cost-rows", type=int, default=0,
+                    help="--packed: merge neighbouring lengths where a segment's fixed launches cost more than the rows the merge pads "
+                         "(rows one segment is worth; 0 = one segment per distinct length)")
     ap.add_argument("--weights-gain", type=float, default=1.0,
                     help="std multiplier of the Linear matrices of the synthetic weights (1 = HF init: near-uniform attention; 2.5 = the "
                          "peaked-attention regime of tests/golden c3_sep).  The line then also reports how many attention workgroups "
@@ -392,7 +395,7 @@ def main():
             return eng.forward_ids_bucketed(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
         if args.packed:        # the pair lengths are host data in the real pipeline (the tokenizer produced them)
             return eng.forward_ids_packed(ids, am, tt, Bq, K, cls, pat, None, granule=args.granule, want_scores=True, want_order=True,
-                                          lengths=host_lengths)
+                                          lengths=host_lengths, segment_cost_rows=args.segment_cost_rows)
         return eng.forward_ids(ids, am, tt, Bq, K, cls, pat, None, want_scores=True, want_order=True)
 
     def fence():
@@ -474,7 +477,8 @@ def main():
                        "queries_per_step": Bq, "pairs_per_step": N, "token_regime": args.regime,
                        **({"execution": f"length-bucketed: {int(out['bucket_rows'])} of {N * S} padded rows computed per step"}
                           if args.bucketed else
-                          {"execution": f"packed rows (granule {args.granule}, pair lengths known on the host): {int(out['packed_rows'])} of {N * S} padded rows computed per step"}
+                          {"execution": f"packed rows (granule {args.granule}, segment_cost_rows {args.segment_cost_rows}, pair lengths known on the host): "
+                                        f"{int(out['packed_rows'])} of {N * S} padded rows computed per step in {int(out.get('packed_segments', 0))} segments"}
                           if args.packed else {}),
                        "parallelism": (f"REHEARSAL: {world} ranks time-sharing ONE GPU, logits exchanged over gloo through the host; "
                                        "not a scaling measurement") if args.rehearse_one_gpu else

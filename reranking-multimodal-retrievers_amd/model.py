@@ -367,7 +367,7 @@ class RerankEngine:
                            Bq: int, K: int, image_cls: Optional[torch.Tensor] = None,
                            image_patches: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                            granule: int = 16, want_scores: bool = False, want_order: bool = False,
-                           lengths: Optional[Sequence[int]] = None):
+                           lengths: Optional[Sequence[int]] = None, segment_cost_rows: int = 0):
         """The same result as `forward_ids` on right-padded pairs, computed over PACKED rows (rr_forward_packed): the pairs are
         grouped by their length rounded up to a multiple of `granule` and laid out group after group, so that every GEMM /
         LayerNorm pass of a layer runs once over the rows that exist — the reference pads every pair to
@@ -378,7 +378,8 @@ class RerankEngine:
         to forward_ids for text-only models.  `lengths`: the pairs' token counts (1 + index of the last non-pad position) as
         the HOST knows them from the tokenizer (pair_inputs.prepare_full_context_inputs keeps them); without it they are
         derived on the device and the group counts cost one device -> host copy per call, which drains the stream between
-        two forwards.  Returns the dict of forward_ids plus `packed_rows`."""
+        two forwards.  `segment_cost_rows`: merge neighbouring lengths where a segment's fixed launches cost more than the rows
+        the merge pads (pair_inputs.group_pairs_by_length).  Returns the dict of forward_ids plus `packed_rows`, `packed_segments`."""
         dev = self.device
         N, S = input_ids.shape
         assert N == Bq * K and granule > 0
@@ -386,7 +387,7 @@ class RerankEngine:
         if lengths is None:                                            # derived on the device: one device -> host copy
             cols = torch.arange(1, S + 1, device=dev)
             lengths = (((input_ids != 0) | (attention_mask != 0)) * cols).amax(1).cpu().numpy()
-        order_h, seg_n, seg_len = group_pairs_by_length(lengths, S, granule, floor)
+        order_h, seg_n, seg_len = group_pairs_by_length(lengths, S, granule, floor, segment_cost_rows)
         assert len(order_h) == N, "one length per pair"
         order = torch.from_numpy(order_h).to(dev, non_blocking=True)
         parts = [[], [], []]
@@ -417,6 +418,7 @@ class RerankEngine:
         out = self.head(logits, logits2 if two else None, labels, Bq, K, want_scores=want_scores, want_order=want_order)
         out["logits"], out["logits2"] = logits, logits2
         out["packed_rows"] = sum(n * s for n, s in zip(seg_n, seg_len))
+        out["packed_segments"] = len(seg_n)
         return out
 
     def activation_range_exceeded(self, reset: bool = True) -> bool:

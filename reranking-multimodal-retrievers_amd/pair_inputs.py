@@ -110,14 +110,19 @@ class NativePairTokenizer:
         return {"input_ids": out[0], "attention_mask": out[1], "token_type_ids": out[2]}
 
 
-def group_pairs_by_length(lengths, padded_len: int, granule: int, min_len: int = 1):
+def group_pairs_by_length(lengths, padded_len: int, granule: int, min_len: int = 1, segment_cost_rows: int = 0):
     """Host side of the packed forward (rr_forward_packed): pairs -> segments of equal row length.
     `lengths[i]` = token count of pair i (1 + index of its last non-pad position, as the tokenizer knows it), clipped to
     [1, padded_len]; a pair goes to the smallest multiple of `granule` (at least `min_len`: the mapping network's
     cross-attention window when image features are present; at most `padded_len`) that holds it.
     Returns (order, seg_pairs, seg_len): `order` lists the pair indices segment after segment (ascending length, input order
     kept inside a segment: a stable sort), seg_pairs / seg_len one entry per NON-EMPTY segment.  The reference pads every
-    pair to padded_len (utils.py:157-165): one segment of that length."""
+    pair to padded_len (utils.py:157-165): one segment of that length.
+    `segment_cost_rows` > 0: every segment costs the forward a fixed number of small launches (embeddings, masks, gathers, the
+    CLS attention: ~140 us on an MI355X), so neighbouring lengths are MERGED where that is cheaper than the rows the merge pads:
+    the segmentation of the sorted lengths that minimises (rows computed + segment_cost_rows x segments), by dynamic
+    programming over the <= padded_len / granule distinct lengths.  Any grouping computes the same logits (a pair only has to
+    fit its segment's length)."""
     import numpy as np
     if granule <= 0 or padded_len <= 0:
         raise ValueError("granule and padded_len must be positive")
@@ -127,4 +132,23 @@ def group_pairs_by_length(lengths, padded_len: int, granule: int, min_len: int =
     order = np.argsort(which, kind="stable")
     counts = np.bincount(which, minlength=len(sizes))
     keep = counts > 0
-    return order, counts[keep].tolist(), sizes[keep].tolist()
+    cnt, szs = counts[keep].tolist(), sizes[keep].tolist()
+    if segment_cost_rows > 0 and len(cnt) > 1:
+        m = len(cnt)
+        pre = [0]
+        for c in cnt:
+            pre.append(pre[-1] + c)
+        best = [0.0] + [float("inf")] * m          # best[j] = cheapest segmentation of the first j lengths
+        cut = [0] * (m + 1)
+        for j in range(1, m + 1):
+            for i in range(j):                        # last segment = lengths i .. j-1, run at length szs[j-1]
+                c = best[i] + (pre[j] - pre[i]) * szs[j - 1] + segment_cost_rows
+                if c < best[j]:
+                    best[j], cut[j] = c, i
+        segs, j = [], m
+        while j > 0:
+            segs.append((cut[j], j))
+            j = cut[j]
+        segs.reverse()
+        cnt, szs = [pre[j] - pre[i] for i, j in segs], [szs[j - 1] for i, j in segs]
+    return order, cnt, szs

@@ -70,3 +70,26 @@ def test_group_pairs_by_length_segments():
     import pytest
     with pytest.raises(ValueError):
         group_pairs_by_length([1], 64, 0)
+
+
+def test_segment_merging_is_valid_and_optimal():
+    """group_pairs_by_length(segment_cost_rows > 0): every pair still fits its segment, the order is the unmerged one, and the
+    segmentation minimises rows + cost x segments (checked against brute force over all cuts of a small case)."""
+    import itertools
+    import numpy as np
+    from rmr_amd.pair_inputs import group_pairs_by_length
+    rng = np.random.default_rng(3)
+    ln = rng.integers(5, 130, 200)
+    o0, n0, l0 = group_pairs_by_length(ln, 128, 16, 1, 0)
+    for lam in (1, 50, 400, 5000, 10 ** 7):
+        o, n, l = group_pairs_by_length(ln, 128, 16, 1, lam)
+        assert (o == o0).all() and sum(n) == len(ln) and l == sorted(l) and l[-1] == l0[-1]
+        pos = 0
+        for cnt, L in zip(n, l):
+            assert (ln[o[pos:pos + cnt]] <= L).all()
+            pos += cnt
+        cost = sum(a * b for a, b in zip(n, l)) + lam * len(n)
+        best = min(sum(sum(n0[i:j]) * l0[j - 1] for i, j in zip((0,) + cuts, cuts + (len(n0),))) + lam * (len(cuts) + 1)
+                   for r in range(len(n0)) for cuts in itertools.combinations(range(1, len(n0)), r))
+        assert cost == best
+    assert len(group_pairs_by_length(ln, 128, 16, 1, 10 ** 7)[1]) == 1           # everything in one padded segment
