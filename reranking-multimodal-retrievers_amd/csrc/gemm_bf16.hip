@@ -33,7 +33,7 @@
 // happen only for a value that never occurs, bit 1 = its residual loads are replaced by register constants, bit 2 = no LayerNorm
 // statistics (no cross-lane sums, no partial store) — what each part costs the launch (profiles/r05_e_*); bit 3 = the `lo` half is
 // loaded and stored for every second ROW of a pass only (whole cache lines skipped) (WRONG results: what a residual stream of 3 instead of 4 bytes per element
-// would buy, profiles/r05_r_*).
+// would buy, profiles/r05_r_*); bit 4 = the statistics are computed but their partial (mean, M2) store is skipped (profiles/r05_u_*).
 #ifndef RR_EPI_DIAG
 #define RR_EPI_DIAG 0
 #endif
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
               for (int j = 0; j < 8; ++j) q += (f[j] - mg) * (f[j] - mg);
             }
             const float m2 = row16_sum(q);
-            if (st_ok && (tid & 15) == 0) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
+            if (st_ok && (tid & 15) == 0 && ((RR_EPI_DIAG & 16) == 0 || mg == 1.2345e38f)) ln.part[(size_t)gm * ln.nparts + grp] = make_float2(mg, m2);
           }
         }
         EP_ADD(8)
