@@ -165,6 +165,8 @@ _MHA = [multi_head_attention]
 _FOLD = [False]
 _FP8 = [False]
 _FP8_DOWN = [False]
+_FP8_FIRST = [0]             # "fp8_first_layer": layers below it keep the (folded) 16-bit dataflow
+_FP8_QKV = [True]            # "fp8_qkv": e4m3 QKV where the previous layer left e4m3 rows
 FP8_GELU_MUL = 8.0          # static scale of the e4m3 GELU output (rr_api.hip FP8_GELU_MUL)
 
 
@@ -200,8 +202,10 @@ class device_rounding:
     the encoder stacks (`encoder_stack`) run with LayerNorm folded into the consumer GEMMs, i.e. the 16-bit operand
     of QKV / FFN-up is the RAW pre-LayerNorm row and the normalisation happens on the fp32 accumulators."""
 
-    def __init__(self, dtype=torch.bfloat16, fold: bool = True, fp8: bool = False, fp8_down: bool = False):
+    def __init__(self, dtype=torch.bfloat16, fold: bool = True, fp8: bool = False, fp8_down: bool = False, fp8_first: int = 0,
+                 fp8_qkv: bool = True):
         self.dtype, self.fold, self.fp8, self.fp8_down = dtype, fold and not fp8, fp8, fp8 and fp8_down   # fp8_down: FFN-down e4m3 too
+        self.fp8_first, self.fp8_qkv = int(fp8_first), bool(fp8_qkv)      # the handle options of the same names (whole stack: 0 / True)
 
     def __enter__(self):
         _MHA.append(multi_head_attention_bf16)
@@ -209,6 +213,8 @@ class device_rounding:
         _FOLD.append(self.fold)
         _FP8.append(self.fp8)
         _FP8_DOWN.append(self.fp8_down)
+        _FP8_FIRST.append(self.fp8_first)
+        _FP8_QKV.append(self.fp8_qkv)
         return mm_bf16
 
     def __exit__(self, *a):
@@ -217,6 +223,8 @@ class device_rounding:
         _FOLD.pop()
         _FP8.pop()
         _FP8_DOWN.pop()
+        _FP8_FIRST.pop()
+        _FP8_QKV.pop()
         return False
 
 
@@ -243,17 +251,39 @@ def encoder_stack(h: Tensor, w: Dict[str, Tensor], prefix: str, n_layers: int, h
     layer 0's QKV takes the normalised embedding rows; every FFN-up and every later QKV takes the raw rows of the
     LayerNorm's input with the LayerNorm applied after the GEMM; residuals are the exact fp32 LayerNorm values."""
     if _FP8[-1] and mm is not None:
+        # rr_config.fp8 with the handle options "fp8_first_layer" / "fp8_qkv" (rr_api.hip run_layer): layers below `first` run the
+        # folded 16-bit dataflow, layers from it on take e4m3 operands for FFN-up and — where the previous layer was an e4m3 layer too
+        # and "fp8_qkv" is on — for QKV; the first e4m3 layer behind a folded one reads that layer's raw rows through the folded QKV.
+        # ("fp8_first_layer" is an option of the TEXT encoder; the cross-encoder's layers always run the e4m3 configuration)
+        first, qkv8 = (_FP8_FIRST[-1] if "context_text_encoder" in prefix else 0), _FP8_QKV[-1]
+        pre = g = b = None                      # raw input of the previous (folded) layer's output LayerNorm and its affine
+        prev8 = False
         for i in range(n_layers):
             p = f"{prefix}.{i}"
-            if i == 0:
-                q, k, v = (linear(h, w, p + ".attention.self." + n, mm) for n in ("query", "key", "value"))
-            else:
+            this8 = i >= first
+            if pre is not None:
+                q, k, v = (folded_linear(pre, g, b, eps, w[p + f".attention.self.{n}.weight"], w[p + f".attention.self.{n}.bias"],
+                                         _QSCALE if n == "query" else 1.0) for n in ("query", "key", "value"))
+            elif prev8 and this8 and qkv8:
                 q, k, v = (linear_fp8(h, w, p + ".attention.self." + n) for n in ("query", "key", "value"))
+            else:
+                q, k, v = (linear(h, w, p + ".attention.self." + n, mm) for n in ("query", "key", "value"))
             ctx = _MHA[-1](q, k, v, heads, add_mask)
-            a = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + h, w, p + ".attention.output.LayerNorm", eps)
-            inter = gelu_erf(linear_fp8(a, w, p + ".intermediate.dense"))
-            down = linear_fp8_static(inter, w, p + ".output.dense") if _FP8_DOWN[-1] else linear(inter, w, p + ".output.dense", mm)
-            h = layer_norm(down + a, w, p + ".output.LayerNorm", eps)
+            if this8:
+                a = layer_norm(linear(ctx, w, p + ".attention.output.dense", mm) + h, w, p + ".attention.output.LayerNorm", eps)
+                inter = gelu_erf(linear_fp8(a, w, p + ".intermediate.dense"))
+                down = linear_fp8_static(inter, w, p + ".output.dense") if _FP8_DOWN[-1] else linear(inter, w, p + ".output.dense", mm)
+                h = layer_norm(down + a, w, p + ".output.LayerNorm", eps)
+                pre = None
+            else:
+                pre1 = linear(ctx, w, p + ".attention.output.dense", mm) + h
+                g1, b1 = w[p + ".attention.output.LayerNorm.weight"], w[p + ".attention.output.LayerNorm.bias"]
+                a = F.layer_norm(pre1, (pre1.shape[-1],), g1, b1, eps)
+                inter = gelu_erf(folded_linear(pre1, g1, b1, eps, w[p + ".intermediate.dense.weight"], w[p + ".intermediate.dense.bias"]))
+                pre = linear(inter, w, p + ".output.dense", mm) + a
+                g, b = w[p + ".output.LayerNorm.weight"], w[p + ".output.LayerNorm.bias"]
+                h = F.layer_norm(pre, (pre.shape[-1],), g, b, eps)
+            prev8 = this8
             if taps is not None:
                 taps[f"{tap_name}{i}"] = h
         return h

@@ -313,6 +313,17 @@ def test_fp8_forward_small_model_against_the_oracle_emulation(dt):
     assert d_emu <= max(2e-3, 0.5 * e_ref)          # same rounding points: well inside the e4m3 drift itself
     assert d_ref <= 2.0 * e_ref + 1e-3
     assert r["order"].cpu().tolist() == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
+    # the subset options ("fp8_first_layer", "fp8_qkv"): layers below the first e4m3 layer run the folded 16-bit dataflow, the first
+    # e4m3 layer reads its predecessor's raw rows through the folded QKV — against the oracle with the same choices
+    for first, qkv in ((1, 1), (2, 1), (3, 1), (0, 0), (1, 0)):
+        eng.set_option("fp8_first_layer", first)
+        eng.set_option("fp8_qkv", qkv)
+        got_s = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K)["logits"].cpu()
+        with torch.no_grad(), O.device_rounding(torch.float16 if dt == "fp16" else torch.bfloat16, fp8=True, fp8_first=first, fp8_qkv=bool(qkv)) as mm:
+            emu_s = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, mm=mm).logits.reshape(-1)
+        d_s, e_s = (got_s - emu_s).abs().max().item(), (emu_s - ref).abs().max().item()
+        print(f"[fp8 small/{dt}] first e4m3 layer {first}, e4m3 QKV {qkv}: device vs same-choice oracle {d_s:.2e}; that oracle vs fp32 {e_s:.2e}")
+        assert torch.isfinite(got_s).all() and d_s <= max(2e-3, 0.5 * e_s)
 
 
 # Gates of the e4m3 drift on c5_full for the WHOLE-STACK form ("fp8_first_layer" = 0), FROZEN at absolute numbers since round 4

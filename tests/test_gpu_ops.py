@@ -494,6 +494,40 @@ def test_gemm_rows_do_not_depend_on_where_their_tile_lies(lib, dt):
         lib.rr_set_op_dtype(0)
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_small_grid_half_row_tiles_are_bit_identical(lib, dt):
+    """Below two 128 x 128 workgroups per CU the two-stage kernel runs 64 x 128 tiles (gemm_bf16.hip half_rows, the strong-scaling
+    shard shapes): tile shape moves time only — every epilogue of the shard step's small GEMMs, with the switch off and on
+    (rr_set_tuning "gemm_small_half_rows"), bit for bit, incl. ragged last tiles."""
+    t16 = torch.float16 if dt else torch.bfloat16
+    assert lib.rr_set_op_dtype(dt) == 0
+    try:
+        for (M, N, K) in [(6656, 768, 768), (6656, 768, 3072), (777, 1024, 256), (13, 768, 768)]:
+            g = torch.Generator(device="cpu").manual_seed(M + N + K + dt)
+            A = (torch.randn(M, K, generator=g) * 0.7).to(t16).cuda()
+            W = (torch.randn(N, K, generator=g) * 0.05).to(t16).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            R = torch.randn(M, N, generator=g).cuda()
+            outs = {}
+            for on in (0, 1):
+                assert lib.rr_set_tuning(b"gemm_small_half_rows", on) == 0
+                res = []
+                for epi in (0, 1, 2):
+                    o = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if epi == 2 else t16)
+                    assert lib.rr_op_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), M, N, K, epi, o.data_ptr(), _stream()) == 0
+                    res.append(o)
+                o = torch.full((M, N), float("nan"), device="cuda")
+                assert lib.rr_op_gemm_resid_f32(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), M, N, K, o.data_ptr(), _stream()) == 0
+                res.append(o)
+                torch.cuda.synchronize()
+                outs[on] = res
+            for a, c in zip(outs[0], outs[1]):
+                assert torch.isfinite(a.float()).all() and torch.equal(a, c), (M, N, K)
+    finally:
+        lib.rr_set_tuning(b"gemm_small_half_rows", 1)
+        lib.rr_set_op_dtype(0)
+
+
 def test_gemm_production_kernel_equals_simple_kernel_at_bench_shape(lib):
     """The four bert-base GEMM shapes at a bench-sized M (heuristic -> half-tile-ring kernel) against the simple
     128x128 loop on the same operands: same products and fp32 accumulation, only the summation order differs."""
