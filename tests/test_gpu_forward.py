@@ -789,3 +789,49 @@ def test_lightning_checkpoint_keys_load_through_the_prefix():
                                             arch=arch))
     m.load_state_dict(ck, prefix="reranker.")
     assert torch.equal(m.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), g["K"] - 1, img[0].cuda(), img[1].cuda()).logits.reshape(-1), lb)
+
+
+@pytest.mark.parametrize("loss", ["BCE", "negative_sampling", "2H_BCE"])
+def test_degenerate_lists_and_pairs(loss):
+    """Edge cases of the input contract (the reference has no tests of its own for this path; these are the degenerate shapes its
+    executor can produce): a list of ONE candidate per query (K = 1: the listwise softmax over a single logit, Recall trivially 1), a
+    candidate that is EMPTY after truncation ([CLS] q [SEP] [SEP] + padding), a pair whose attention mask is all zero behind [CLS]
+    (every key but one masked), and identical candidates (ties keep retrieval order).  fp16 against the fp32 oracle with
+    north_star's 1e-3; rank == stable descending sort of the device logits."""
+    g = load_golden("tiny_mm")
+    cfg, vision = g["cfg"], g["vision"]
+    cfg.loss_fn = loss
+    w = O.make_weights(cfg, seed=0, vision=vision)
+    eng = _engine(cfg, vision, w, "fp16")
+    S = g["S"]
+    for Bq, K in ((3, 1), (2, 4)):
+        ids, am, tt = O.make_pair_batch(cfg, Bq, K, S, seed=17, regime="realistic")
+        img = O.make_image_feats(cfg, Bq, seed=17) if vision else (None, None)
+        N = Bq * K
+        # an empty candidate: keep the query span, then [SEP] [SEP], rest padding
+        sep = int(ids[0][(ids[0] != 0).nonzero().max()])
+        qend = int((tt[0] == 1).nonzero().min()) if (tt[0] == 1).any() else S // 2
+        ids[0, qend:] = 0; am[0, qend:] = 0; tt[0, qend:] = 0
+        ids[0, qend] = sep; am[0, qend] = 1; tt[0, qend] = 1
+        # a pair with nothing but [CLS] visible
+        ids[N - 1, 1:] = 0; am[N - 1, 1:] = 0; tt[N - 1, :] = 0
+        if K >= 4:
+            ids[K + 2], am[K + 2], tt[K + 2] = ids[K + 1].clone(), am[K + 1].clone(), tt[K + 1].clone()      # a tie inside query 1
+        labels = [1.0] + [0.0] * (K - 1)
+        labels = labels * Bq
+        lab = None if loss == "negative_sampling" else torch.tensor(labels).cuda()
+        r = eng.forward_ids(ids.cuda(), am.cuda(), tt.cuda(), Bq, K, None if img[0] is None else img[0].cuda(),
+                            None if img[1] is None else img[1].cuda(), lab, want_scores=True, want_order=True)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = O.full_context_forward(cfg, w, ids, am, tt, Bq, K, img[0], img[1], None if loss == "negative_sampling" else labels)
+        got = r["logits"].cpu().reshape(-1)
+        want = ref.logits.reshape(-1) if loss != "2H_BCE" else ref.logits.reshape(-1)
+        d = (got - want).abs().max().item()
+        print(f"[degenerate/{loss} Bq={Bq} K={K}] |dlogit| vs fp32 oracle {d:.2e}; loss {r['loss'].item():.5f} vs {ref.loss.item():.5f}")
+        assert torch.isfinite(got).all() and d <= TOL_FP16
+        assert abs(r["loss"].item() - ref.loss.item()) < 2e-3
+        order = r["order"].cpu().tolist()
+        assert order == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
+        if K >= 4:
+            assert got[K + 2].item() == got[K + 1].item() and order[1].index(1) < order[1].index(2)
