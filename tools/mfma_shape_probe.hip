@@ -80,6 +80,44 @@ __global__ __launch_bounds__(512) void probe(const uint4* __restrict__ src, floa
   if (keep == 1.2345e-30f) sink[blockIdx.x * 512 + tid] = keep;
 }
 
+// One wave per SIMD (256-thread workgroup, up to 512 registers per lane): a 128 x 128 x 32 wave tile — 64 MFMAs of 16x16x32 on 256
+// accumulator registers, 16 fragment reads per iteration = 8 ds_read_b128 per 32 MFMAs against the two-waves-per-SIMD tile's 12.
+template <bool LDS>
+__global__ __launch_bounds__(256) void probe_w4(const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
+  __shared__ __attribute__((aligned(16))) uint4 tile[4096];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += 256) tile[i] = src[(blockIdx.x * 4096 + i) & 0xfffff];
+  __syncthreads();
+  f16x8 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(f16x8, tile[(tid * 13 + i * 517) & 4095]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(f16x8, tile[(tid * 7 + i * 911 + 3) & 4095]);
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (LDS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = __builtin_bit_cast(f16x8, tile[(tid + it * 64 + i * 512) & 4095]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(f16x8, tile[(tid + it * 64 + i * 512 + 256) & 4095]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+  }
+  float keep = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][3];
+  if (keep == 1.2345e-30f) sink[blockIdx.x * 256 + tid] = keep;
+}
+
 int main() {
   const int n = 1 << 20;
   std::vector<uint16_t> h(n * 8);
@@ -105,11 +143,26 @@ int main() {
              iters * cyc_per_it_at_peak / (ms * 1e-3) / 1e9);
     }
   };
+  auto run4 = [&](auto kern, const char* name) {
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, sink, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double fl = 2.0 * 128 * 128 * 32 * (double)iters * 4 * grid;     // one 128 x 128 x 32 wave tile per iteration and wave, four waves per CU
+      printf("%-34s rep %d: %8.2f ms  %7.1f TFLOP/s  (clock if the matrix pipe were always busy: %.2f GHz)\n", name, rep, ms, fl / ms / 1e9,
+             iters * 64.0 * 16.0 / (ms * 1e-3) / 1e9);
+    }
+  };
   run(probe<16, false>, "16x16x32 f16, registers only");
   run(probe<32, false>, "32x32x16 f16, registers only");
   run(probe<16, true>, "16x16x32 f16 + 12 ds_read_b128");
   run(probe<32, true>, "32x32x16 f16 + 12 ds_read_b128");
   run(probe<16, false>, "16x16x32 f16, registers only");
   run(probe<32, false>, "32x32x16 f16, registers only");
+  run4(probe_w4<false>, "1 wave/SIMD 128x128, registers only");
+  run4(probe_w4<true>, "1 wave/SIMD 128x128 + 16 ds_read");
+  run(probe<16, true>, "16x16x32 f16 + 12 ds_read_b128");
+  run4(probe_w4<true>, "1 wave/SIMD 128x128 + 16 ds_read");
   return 0;
 }
