@@ -191,8 +191,13 @@ int rr_set_padded_seq_len(rr_handle h, int padded_seq_len);
  *   "ln_lite"        0 | 1                  1         1: residuals are recomputed from LayerNorm statistics; 0: every LayerNorm
  *                                                     writes its fp32 output and the residual GEMMs read it back (reference dataflow)
  *   "ln_fold"        0 | 1                  1         1: LayerNorm folded into the consumer GEMMs (QKV, FFN-up); 0: LayerNorm kernels
- *   "resid_split"    0 | 1                  1         1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + fp16 lo
+ *   "resid_split"    0 | 1                  1         1: pre-LayerNorm rows between the residual epilogues as 16-bit hi + lo
  *                                                     (where the persistent ring runs); 0: fp32 rows
+ *   "resid_lo8"      0 | 1                  by dtype  form of that lo half.  1: e5m2 bytes of (x - hi) * 16 (6 bytes per element through
+ *                                                     the residual epilogues instead of 8: -1.6 % step time at the bench shape; x kept to
+ *                                                     >= 14 significant bits behind an fp16 hi, 11 behind a bf16 hi); 0: fp16 (22 / 19
+ *                                                     bits).  Default: 1 for fp16 handles (drift against the fp32 goldens unchanged),
+ *                                                     0 for bf16 handles (it would add ~20 % to theirs)
  *   "ce_cls_only"    0 | 1                  1         1: the cross-encoder's last layer computes queries / FFN for the CLS row of a
  *                                                     pair only (all the classifiers read, utils.py:105-108); 0: every row
  *   "fp8_ffn_down"   0 | 1                  0         rr_config.fp8 only: FFN-down on the e4m3 ring too (GELU output as e4m3 under a

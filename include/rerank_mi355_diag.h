@@ -98,7 +98,10 @@ int rr_op_gemm_resid_lnprep(const uint16_t* A, const uint16_t* W, const float* b
  * operand rounding (the consumer GEMM's A rows) + lo = fp16(x - hi) instead of a separate fp32 copy.  Residual rows come in as
  * (hi_in, lo_in) [M,N] — normalised on the fly with (ln_stats [M,2], ln_gamma, ln_beta) when ln_stats != NULL — and the output
  * rows x = A W^T + bias + residual leave as (x16_out, lo_out) plus their statistics; hi_in == x16_out and lo_in == lo_out
- * (in place) is allowed.  Only for shapes the persistent ring kernel runs (>= 128 tiles of 256 x 256 — rr_set_tuning "gemm_ring_min_tiles" —, N % 8 == 0), otherwise
+ * (in place) is allowed.  With the process-wide "resid_lo8" in effect (rr_set_tuning; default: on for the fp16 operand type) lo_in /
+ * lo_out are e5m2 BYTES of (x - hi) * 16 in the epilogues' private layout — rows r and r + 16 of an aligned 32-row group
+ * interleaved in units of 8 columns, ceil(M / 32) * 32 rows of N bytes (csrc/rr_common.h lo8_pair_offset; tests/test_gpu_ops.py
+ * _lo8_to_device_layout).  Only for shapes the persistent ring kernel runs (>= 128 tiles of 256 x 256 — rr_set_tuning "gemm_ring_min_tiles" —, N % 8 == 0), otherwise
  * RR_ERR_UNSUPPORTED. */
 int rr_op_gemm_resid_split(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* hi_in, const uint16_t* lo_in,
                            const float* ln_stats, const float* ln_gamma, const float* ln_beta, int M, int N, int Kd, float eps,
@@ -119,7 +122,7 @@ int rr_op_layernorm_q8(const float* x, const float* gamma, const float* beta, fl
 int rr_util_quantize_rows_e4m3(const float* w_host, int rows, int cols, uint8_t* out_host, float* scales_host);
 int rr_set_gemm_variant(int variant);
 /* Process-wide DIAGNOSTIC switches (A/B tools, tests): the default every handle option of the same name follows until
- * rr_set_option pins it ("ln_lite", "ln_fold", "resid_split", "ce_cls_only", "fp8_ffn_down", "attn_fixed_ref": see rr_set_option),
+ * rr_set_option pins it ("ln_lite", "ln_fold", "resid_split", "resid_lo8", "ce_cls_only", "fp8_ffn_down", "attn_fixed_ref": see rr_set_option),
  * plus switches that select between bit-identical kernels or only move time: "resid_fast" (default 1: plain fp32 residual GEMMs
  * on the split forms' epilogue), "resid_touch" (0: L2 touch of the next residual pass), "gemm_desync" (0: start skew of the XCDs,
  * percent of a tile period), "persistent_gemm" (1), "gemm_ring_min_tiles" (128: smallest problem, in 256 x 256 tiles, on the

@@ -119,7 +119,7 @@ struct LnResid {
   int nparts;            // ceil(N / 128)
   const float2* in_stats;
   const float* csum;
-  int flags;             // bit 0: touch the next pass's residual lines a pass ahead (rr_set_tuning "resid_touch")
+  int flags;             // bit 0: touch the next pass's residual lines a pass ahead (rr_set_tuning "resid_touch"); bit 1: the lo half of the split stream is 8-bit (GemmFold::lo_bits)
   // split residual stream (GemmFold, rr_common.h): residual rows as hi + lo, output rows as x16 + lo_out
   const bf16_t* r_hi;
   const bf16_t* r_lo;
@@ -840,7 +840,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_h(const bf16_t* __restrict__ 
 // main loop's last barrier); the epilogue stages through the other half of the LDS ([80 KiB, 160 KiB), two 128-row passes
 // for 16-bit output, four 64-row passes for fp32), so the 5-6k-cycle cold prologue of every tile but the first hides
 // behind the previous tile's epilogue.  Same main loop, same arithmetic, same results as gemm_kernel_h.
-// SPLIT (EPI_BIAS_RESID_F32 only): bit 0 = the residual rows come as the (hi, lo) pair, bit 1 = the output rows leave as one.
+// SPLIT (EPI_BIAS_RESID_F32 only): bit 0 = the residual rows come as the (hi, lo) pair, bit 1 = the output rows leave as one,
+// bit 3 = the lo half (in and out) is the 8-bit e5m2 form of rr_common.h (GemmFold::lo_bits == 8) instead of fp16.
 // DIAG (tools/bench_gemm.py --epilogue-timeline): 1 = per-wave s_memtime marks around the sections of the epilogue, summed over the
 // workgroup's tiles; 2 = also the 13 marks per K-tile of the main loop (they cost the loop ~11 %).  0 in every product launch.
 // FOLD: the folded-LayerNorm consumer form (ln.in_stats / ln.csum given) — a compile-time choice so that the accumulator
@@ -1320,9 +1321,21 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
       if (cm0 + 256 > M || cn0 + 256 > N) return;                   // ragged last tiles: not worth a clamp per lane
       const size_t row0 = (size_t)(cm0 + (pass_ >> 1) * 128 + (pass_ & 1) * 64);
       if constexpr ((SPLIT & 1) != 0) {   // split residual: 64 rows x 512 B of hi (waves 0-3) and of lo (waves 4-7), one 128-byte line per thread
+        if constexpr ((SPLIT & 8) != 0) {   // 8-bit lo: 64 rows x 256 B = 128 lines (waves 4-5)
+          if (wave < 4) {
+            const bf16_t* sb = ln.r_hi + row0 * ln.ld16 + cn0;                                          // scalar
+            const uint32_t vo = (uint32_t)((((tid & 255) >> 2) * ln.ld16 + (tid & 3) * 64) * 2);
+            glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+          } else if (wave < 6) {             // the pass's 32 row PAIRS (lo8_pair_offset) x 512 B
+            const uint8_t* sb = (const uint8_t*)ln.r_lo + (row0 >> 5) * 16 * (size_t)(2 * ln.ld16) + cn0 * 2;   // scalar
+            const uint32_t vo = (uint32_t)(((tid & 127) >> 2) * (2 * ln.ld16) + (tid & 3) * 128);
+            glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+          }
+        } else {
         const bf16_t* sb = (wave < 4 ? ln.r_hi : ln.r_lo) + row0 * ln.ld16 + cn0;                     // scalar
         const uint32_t vo = (uint32_t)((((tid & 255) >> 2) * ln.ld16 + (tid & 3) * 64) * 2);
         glds4_so(sb, vo, __builtin_amdgcn_readfirstlane(lds_base + 5 * HALF + ROWS * PITCH + wave * 256));
+        }
       } else {
         const float* sb = resid + row0 * ldr + cn0;                                                     // scalar
         const uint32_t vo = (uint32_t)(((tid >> 3) * ldr + (tid & 7) * 32) * 4);                        // line `tid` of the 64 x 256 block
@@ -1339,7 +1352,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
     const int c8 = tid & 31, gcol8 = cn0 + c8 * 8;
     const bool col_ok8 = gcol8 < N;                                   // N % 8 == 0: a chunk is inside or outside as a whole
     constexpr bool SPLIT_EPI = (EPI == EPI_BIAS_RESID_F32 && SPLIT != 0);
-    uint4 rh[SPLIT_EPI ? UN8 : 1], rl[SPLIT_EPI ? UN8 : 1];
+    constexpr bool LO8 = SPLIT_EPI && (SPLIT & 8) != 0;
+    constexpr float LO8_MX = 1.0f / (float)(1 << RR_LO8_SHIFT);      // the MX scale of the e5m2 lo bytes (rr_common.h)
+    uint4 rh[SPLIT_EPI ? UN8 : 1], rl[(SPLIT_EPI && !LO8) ? UN8 : 1];
+    uint4 rl8[LO8 ? UN8 / 2 : 1];                                      // one 16-byte chunk = 8 columns of rows r and r + 16 (lo8_pair_offset)
     float4 ra[(SPLIT_EPI && !(SPLIT & 1)) ? UN8 : 1], rb[(SPLIT_EPI && !(SPLIT & 1)) ? UN8 : 1];
     auto issue_resid = [&](int pass_) {
       if constexpr (SPLIT_EPI) {
@@ -1351,6 +1367,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           if constexpr ((SPLIT & 1) != 0 && (RR_EPI_DIAG & 2) != 0) {
             rh[u] = make_uint4(0x3c003c00u + gm, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
             rl[u] = make_uint4(0x10001000u + tid, 0x10001000u, 0x10001000u, 0x10001000u);
+          } else if constexpr ((SPLIT & 1) != 0 && LO8) {
+            rh[u] = ok ? load_stream_u4(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
+            if (!(u & 1)) rl8[u >> 1] = ok ? load_stream_u4((const uint8_t*)ln.r_lo + lo8_pair_offset(gm, gcol8, ln.ld16)) : make_uint4(0u, 0u, 0u, 0u);
           } else if constexpr ((SPLIT & 1) != 0) {
             rh[u] = ok ? load_stream_u4(ln.r_hi + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
             if constexpr ((RR_EPI_DIAG & 8) != 0) rl[u] = (ok && !(u & 1)) ? load_stream_u4(ln.r_lo + (size_t)gm * ln.ld16 + gcol8) : make_uint4(0u, 0u, 0u, 0u);
@@ -1415,13 +1434,29 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
         float4 lg, lb, lg1, lb1;
         load_gb(lg, lb, lg1, lb1);
         if constexpr (DIAG != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        uint32_t l8_even[2] = {0u, 0u};      // 8-bit lo: the bytes of the even row of a pair wait here for the odd row's (one 16-byte store per pair)
         EP_ADD(7)
 #pragma unroll
         for (int u = 0; u < UN8; ++u) {
           const int r = (tid >> 5) + u * 16, gm = row_base + r;
           const bool ok = gm < M && col_ok;
           float x[8];
-          if constexpr ((SPLIT & 1) != 0) {      // x = hi (operand type) + lo (fp16): one v_fma_mix_f32 per element (rr_common.h)
+          if constexpr ((SPLIT & 1) != 0 && LO8) {   // x = hi + e5m2 lo: one scaled unpack per pair, one v_fma_mix_f32 / v_add_f32 per element
+            const uint32_t tok = mix_fence(rh[u], rl8[u >> 1]);
+            const uint32_t hw[4] = {rh[u].x, rh[u].y, rh[u].z, rh[u].w};
+            const uint32_t w0 = (u & 1) ? rl8[u >> 1].z : rl8[u >> 1].x, w1 = (u & 1) ? rl8[u >> 1].w : rl8[u >> 1].y;
+            const float2 l2[4] = {lo8_decode<0>(w0, LO8_MX, tok), lo8_decode<1>(w0, LO8_MX, tok),
+                                  lo8_decode<0>(w1, LO8_MX, tok), lo8_decode<1>(w1, LO8_MX, tok)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if constexpr (DT == 1) {
+                x[2 * j] = mix_add_f16_f32<0>(l2[j].x, hw[j], tok); x[2 * j + 1] = mix_add_f16_f32<1>(l2[j].y, hw[j], tok);
+              } else {
+                const float2 h = unpack2<0>(hw[j]);
+                x[2 * j] = h.x + l2[j].x; x[2 * j + 1] = h.y + l2[j].y;
+              }
+            }
+          } else if constexpr ((SPLIT & 1) != 0) {      // x = hi (operand type) + lo (fp16): one v_fma_mix_f32 per element (rr_common.h)
             const uint32_t tok = mix_fence(rh[u], rl[u]);
             const uint32_t hw[4] = {rh[u].x, rh[u].y, rh[u].z, rh[u].w}, lw[4] = {rl[u].x, rl[u].y, rl[u].z, rl[u].w};
 #pragma unroll
@@ -1453,11 +1488,31 @@ __global__ __launch_bounds__(512) void gemm_kernel_hp(const bf16_t* __restrict__
           uint32_t hi[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) hi[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
+          if constexpr (LO8 && (SPLIT & 2) != 0) {      // row u - 1 was inside the matrix, its partner row u is not: its chunk leaves with a zero second half
+            if ((u & 1) && !ok && gm - 16 < M && col_ok)
+              store_stream((uint8_t*)ln.lo_out + lo8_pair_offset(gm - 16, gcol, ln.ld16), make_uint4(l8_even[0], l8_even[1], 0u, 0u));
+          }
           bool st_ok = ok;
           if constexpr ((RR_EPI_DIAG & 1) != 0) st_ok = ok && f[0] == 1.2345e38f;
           if (st_ok) {
             if constexpr (SPLIT != 4) store_stream(ln.x16 + (size_t)gm * ln.ldx + gcol, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-            if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
+            if constexpr ((SPLIT & 2) != 0 && LO8) {    // lo = e5m2((x - hi) * 2^RR_LO8_SHIFT): x - hi is exact in fp32, one rounding
+              uint32_t l8[2] = {0u, 0u};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float d0, d1;
+                if constexpr (DT == 1) {
+                  d0 = mix_sub_f16<0>(f[2 * j], hi[j]); d1 = mix_sub_f16<1>(f[2 * j + 1], hi[j]);
+                } else {
+                  const float2 hb = unpack2<0>(hi[j]);
+                  d0 = f[2 * j] - hb.x; d1 = f[2 * j + 1] - hb.y;
+                }
+                if (j & 1) l8[j >> 1] = lo8_encode<1>(l8[j >> 1], d0, d1, LO8_MX);
+                else l8[j >> 1] = lo8_encode<0>(l8[j >> 1], d0, d1, LO8_MX);
+              }
+              if (u & 1) store_stream((uint8_t*)ln.lo_out + lo8_pair_offset(gm - 16, gcol, ln.ld16), make_uint4(l8_even[0], l8_even[1], l8[0], l8[1]));
+              else { l8_even[0] = l8[0]; l8_even[1] = l8[1]; }
+            } else if constexpr ((SPLIT & 2) != 0) {    // lo = fp16(x - hi)
               uint32_t lo[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -1679,7 +1734,7 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
     else RR_GEMM_CASE_F(E, false)                                                                             \
     break;                                                                                                    \
   }
-  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
+  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0) | (((ln.r_hi || ln.lo_out) && (ln.flags & 2)) ? 8 : 0);
   if (split && epilogue != EPI_BIAS_RESID_F32) return hipErrorInvalidValue;
 #define RR_GEMM_SPLIT_CASE(S)                                                                                 \
   case S: {                                                                                                   \
@@ -1698,6 +1753,9 @@ hipError_t launch_hp(const bf16_t* A, int lda, const bf16_t* W, int ldw, const f
     RR_GEMM_SPLIT_CASE(1)
     RR_GEMM_SPLIT_CASE(2)
     RR_GEMM_SPLIT_CASE(3)
+    RR_GEMM_SPLIT_CASE(9)
+    RR_GEMM_SPLIT_CASE(10)
+    RR_GEMM_SPLIT_CASE(11)
   }
   // the plain fp32 residual stream (the fp8 configuration's attention-out, folding switched off) on the split forms' epilogue:
   // residual rows requested a pass ahead, 8-column chunks (rr_set_tuning "resid_fast", default 1; bit-identical to the older form)
@@ -1735,7 +1793,7 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
   if (n_cu < 8 || nwg < n_cu) return hipErrorInvalidValue;
   constexpr int lds_bytes = 160 * 1024;
   dim3 grid(n_cu), block(512);
-  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0);
+  const int split = (ln.r_hi ? 1 : 0) | (ln.lo_out ? 2 : 0) | (((ln.r_hi || ln.lo_out) && (ln.flags & 2)) ? 8 : 0);
 #define RR_DIAG_LAUNCH(E, S, F) RR_DIAG_LAUNCH_D(E, S, F, 1)
 #define RR_DIAG_LAUNCH_D(E, S, F, D)                                                                                      \
   {                                                                                                                       \
@@ -1752,6 +1810,7 @@ hipError_t launch_hp_diag(const bf16_t* A, int lda, const bf16_t* W, int ldw, co
     return hipErrorInvalidValue;
   }
   if (epilogue == EPI_BIAS_RESID_F32 && split == 3) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 3, false)
+  if (epilogue == EPI_BIAS_RESID_F32 && split == 11) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 11, false)
   if (epilogue == EPI_BIAS_RESID_F32 && split == 0 && !ln.x16) RR_DIAG_LAUNCH(EPI_BIAS_RESID_F32, 0, false)
   if (epilogue == EPI_BIAS_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_BF16, 0, true)
   if (epilogue == EPI_BIAS_GELU_BF16 && split == 0 && ln.in_stats) RR_DIAG_LAUNCH(EPI_BIAS_GELU_BF16, 0, true)
@@ -1925,11 +1984,12 @@ hipError_t rr_launch_gemm_fold(const bf16_t* A, int lda, const bf16_t* W, int ld
   if ((fold.in_stats != nullptr) != (fold.csum != nullptr)) return hipErrorInvalidValue;
   if (fold.in_stats && (epilogue == EPI_BIAS_RESID_F32)) return hipErrorInvalidValue;
   const LnResid ln{(const float2*)ln_stats, ln_gamma, ln_beta, fold.x16, fold.ldx, (float2*)fold.part, fold.nparts,
-                   (const float2*)fold.in_stats, fold.csum, g_resid_touch.load(), fold.r_hi, fold.r_lo, fold.ld16, fold.lo_out};
+                   (const float2*)fold.in_stats, fold.csum, (g_resid_touch.load() & 1) | (fold.lo_bits == 8 ? 2 : 0), fold.r_hi, fold.r_lo, fold.ld16, fold.lo_out};
   const bool split = fold.r_hi || fold.r_lo || fold.lo_out;
   if (split) {
     if (epilogue != EPI_BIAS_RESID_F32 || (fold.r_hi == nullptr) != (fold.r_lo == nullptr) || (fold.ld16 & 3)) return hipErrorInvalidValue;
     if (!fold.x16 || fold.ldx != fold.ld16 || (fold.ldx & 7) || (N & 7)) return hipErrorInvalidValue;   // the hi half is the x16 rows; 16-byte chunks of 8
+    if (fold.lo_bits != 16 && fold.lo_bits != 8) return hipErrorInvalidValue;
   }
   if (M <= 0 || N <= 0 || Kd <= 0) return hipErrorInvalidValue;
   if (Kd % BK != 0 || (lda & 7) || (ldw & 7) || (N & 3) || (ldc & 3)) return hipErrorInvalidValue;

@@ -87,6 +87,11 @@ __device__ __forceinline__ uint32_t mix_fence(const uint4& a, const uint4& b) {
   asm volatile("s_nop 1\n\tv_mov_b32 %0, 0" : "=v"(t) : "v"(a.x), "v"(b.x));
   return t;
 }
+__device__ __forceinline__ uint32_t mix_fence(const uint4& a, const uint2& b) {
+  uint32_t t;
+  asm volatile("s_nop 1\n\tv_mov_b32 %0, 0" : "=v"(t) : "v"(a.x), "v"(b.x));
+  return t;
+}
 // ---- streaming accesses of the GEMM epilogues.  An output row is written once and next read by another launch, a residual
 // row is read once: neither is worth an L2 line, and the lines they would take are the operand panels the workgroups of an
 // XCD share (RR_NT bit 0: outputs stored with the `nt` hint, bit 1: residual rows loaded with it; measured in DESIGN.md).
@@ -122,6 +127,46 @@ __device__ __forceinline__ float4 load_stream_f4(const void* p) {
   } else {
     return *(const float4*)p;
   }
+}
+__device__ __forceinline__ uint2 load_stream_u2(const void* p) {
+  if constexpr ((RR_NT & 2) != 0) {
+    const u32x2_ v = __builtin_nontemporal_load((const u32x2_*)p);
+    return make_uint2(v.x, v.y);
+  } else {
+    return *(const uint2*)p;
+  }
+}
+// ---- 8-bit `lo` half of the split residual stream (GemmFold::lo_bits == 8): lo = x - hi travels as OCP e5m2 ("bf8") of
+// lo * 2^RR_LO8_SHIFT, converted by gfx950's scaled pack / unpack instructions (the scale operand is the MX block scale 2^-SHIFT:
+// encode divides by it, decode multiplies).  |lo| <= ulp(hi) / 2, so three significant bits of lo put x at 14 (fp16 hi) / 11
+// (bf16 hi) significant bits in the worst case, a power of two beyond what the 16-bit MFMA operand keeps of it anyway; the
+// shift keeps lo * 2^SHIFT a NORMAL e5m2 number (>= 2^-14) for every |x| >= 2^-7 (fp16 hi) and below the e5m2 maximum (57 344)
+// for |x| < 2^22 (fp16 rows end at 6.5e4; bf16 rows beyond 9e5 saturate lo, i.e. fall back to the hi half's precision); smaller
+// x keep an absolute error <= 2^-21.  WORD: 0 / 1 = the low / high 16 bits of the packed dword (two e5m2 values each).
+constexpr int RR_LO8_SHIFT = 4;
+#ifndef RR_RESID_LO8_DEFAULT
+#define RR_RESID_LO8_DEFAULT (-1)   // process-wide default of the "resid_lo8" option (rr_api.hip): -1 = by operand type (fp16: on, bf16: off)
+#endif
+// Memory layout of the 8-bit lo rows, private to the residual epilogues that write and read them: rows r and r + 16 of an aligned
+// group of 32 rows are interleaved in units of 8 columns, so that a lane's 8 columns of BOTH rows are one 16-byte chunk (8-byte
+// accesses reach 0.54 - 0.70 x of the 16-byte rate here).  Byte offset of the chunk that holds columns col .. col + 7 (col % 8 == 0)
+// of row r (r % 32 < 16: first 8 bytes) and row r + 16 (last 8 bytes); ld = columns per row.  The buffer spans ceil(M / 32) * 32 rows.
+__device__ __forceinline__ size_t lo8_pair_offset(int r, int col, int ld) {
+  return ((size_t)(r >> 5) * 16 + (r & 15)) * (size_t)(2 * ld) + (size_t)col * 2;
+}
+template <int WORD>
+__device__ __forceinline__ float2 lo8_decode(uint32_t w, float mx_scale, uint32_t tok) {   // two e5m2 -> fp32, times mx_scale
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  f32x2_ d;
+  if constexpr (WORD == 0) asm("v_cvt_scalef32_pk_f32_bf8 %0, %1, %2" : "=v"(d) : "v"(w), "s"(mx_scale), "v"(tok));
+  else asm("v_cvt_scalef32_pk_f32_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(d) : "v"(w), "s"(mx_scale), "v"(tok));
+  return make_float2(d.x, d.y);
+}
+template <int WORD>
+__device__ __forceinline__ uint32_t lo8_encode(uint32_t old, float a, float b, float mx_scale) {   // e5m2(a / mx_scale), e5m2(b / mx_scale) into half WORD of `old`
+  if constexpr (WORD == 0) asm("v_cvt_scalef32_pk_bf8_f32 %0, %1, %2, %3" : "+v"(old) : "v"(a), "v"(b), "s"(mx_scale));
+  else asm("v_cvt_scalef32_pk_bf8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(old) : "v"(a), "v"(b), "s"(mx_scale));
+  return old;
 }
 __device__ __forceinline__ uint32_t pack2rt(float lo, float hi, int dt) { return dt ? pack2<1>(lo, hi) : pack2<0>(lo, hi); }
 template <int DT>
@@ -305,6 +350,9 @@ struct GemmFold {
   const bf16_t* r_lo = nullptr;
   int ld16 = 0;
   bf16_t* lo_out = nullptr;
+  // 16: lo rows are fp16 [M][ld16]; 8: e5m2 bytes of lo * 2^RR_LO8_SHIFT, [M][ld16] BYTES (r_lo / lo_out point at bytes): the
+  // residual epilogue moves 6 instead of 8 bytes per element and touches 3 instead of 4 cache lines per 64 columns
+  int lo_bits = 16;
 };
 // true when a GEMM with M x N output will run on the kernel that implements the split residual stream
 bool rr_gemm_split_ok(int M, int N);

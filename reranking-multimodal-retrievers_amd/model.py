@@ -567,7 +567,7 @@ class RerankEngine:
         return int(self.lib.rr_workspace_bytes(self.h, n_pairs, S))
 
     def set_option(self, key: str, value: int):
-        """Pin a numerics option of THIS engine (rr_set_option: "ln_lite", "ln_fold", "resid_split", "ce_cls_only",
+        """Pin a numerics option of THIS engine (rr_set_option: "ln_lite", "ln_fold", "resid_split", "resid_lo8", "ce_cls_only",
         "fp8_ffn_down", "fp8_first_layer", "fp8_qkv", "attn_fixed_ref"); -1 = follow the process-wide diagnostic switch again."""
         L.check(self.lib.rr_set_option(self.h, key.encode(), int(value)), self.h, "rr_set_option")
 

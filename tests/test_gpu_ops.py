@@ -314,18 +314,46 @@ def test_attention_long_key_sequences_reload_the_bias_chunk(lib, Tk):
         assert (o - ref).abs().max().item() < 3e-2
 
 
+def _lo8_encode(d):
+    """fp32 differences x - hi -> the e5m2 bytes of the 8-bit lo half (rr_common.h RR_LO8_SHIFT = 4), as torch rounds them."""
+    return (d * 16.0).to(torch.float8_e5m2)
+
+
+def _lo8_decode(b):
+    return b.float() / 16.0
+
+
+def _lo8_to_device_layout(b):
+    """[M, N] e5m2 -> the byte buffer the residual epilogues keep (rr_common.h lo8_pair_offset): rows r and r + 16 of an aligned
+    32-row group interleaved in units of 8 columns; ceil(M / 32) * 32 rows."""
+    M, N = b.shape
+    R = (M + 31) // 32 * 32
+    u = torch.zeros(R, N, dtype=torch.uint8, device=b.device)
+    u[:M] = b.view(torch.uint8)
+    return u.view(R // 32, 2, 16, N // 8, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def _lo8_from_device_layout(buf, M, N):
+    R = (M + 31) // 32 * 32
+    return buf.view(R // 32, 16, N // 8, 2, 8).permute(0, 3, 1, 2, 4).contiguous().view(R, N)[:M].view(torch.float8_e5m2)
+
+
+@pytest.mark.parametrize("lo8", [0, 1])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("K", [128, 768])
-def test_production_split_epilogue_is_bit_exact(lib, dt, K):
+def test_production_split_epilogue_is_bit_exact(lib, dt, K, lo8):
     """Bit-exact detector for the production epilogues gemm_kernel_hp<4, DT, 3> (VERDICT r2 weak-2 / ADVICE r2): the residual
     value the split epilogue forms internally — hi + lo, LayerNorm-recomputed with the epilogue's own expression — is
     produced as fp32 rows by rr_op_split_residual_value, the fp32-stream epilogue (itself bit-equal to the simple kernel,
     test_ln_residual_gemm_is_reproducible...) adds them, and the split epilogue's x16 / lo must equal the roundings of that
     fp32 result BIT FOR BIT (hi = operand rounding, lo = fp16(x - hi): both exact operations), four runs, in place as the
-    forward does.  A lost residual term (the packed-f32 hazard) or any reordering of the epilogue arithmetic shows here."""
+    forward does.  A lost residual term (the packed-f32 hazard) or any reordering of the epilogue arithmetic shows here.
+    lo8 = 1: the same with the 8-bit lo half ("resid_lo8": e5m2 bytes of (x - hi) * 16 by the hardware's scaled pack / unpack) — the
+    decoded residual value is exact in fp16, so the same fp32 reference applies, and the stored bytes must equal torch's
+    round-to-nearest-even e5m2 conversion of the exact difference."""
     M, N = 512 * 256 - 31, 768
     t16 = torch.float16 if dt else torch.bfloat16
-    assert lib.rr_set_op_dtype(dt) == 0
+    assert lib.rr_set_op_dtype(dt) == 0 and lib.rr_set_tuning(b"resid_lo8", lo8) == 0
     try:
         g = torch.Generator().manual_seed(23 + dt + K)
         A = torch.randn(M, K, generator=g).to(t16).cuda()
@@ -333,7 +361,10 @@ def test_production_split_epilogue_is_bit_exact(lib, dt, K):
         b = torch.randn(N, generator=g).cuda()
         X = (torch.randn(M, N, generator=g) * 3 + 0.5).cuda()
         hi = X.to(t16)
-        lo = (X - hi.float()).half()
+        lo_in8 = _lo8_encode(X - hi.float()) if lo8 else None
+        lo = _lo8_decode(lo_in8).half() if lo8 else (X - hi.float()).half()      # (an e5m2 value / 16 is exact in fp16)
+        if lo8:
+            assert torch.equal(lo.float(), _lo8_decode(lo_in8))
         Xs = hi.float() + lo.float()
         eps = 1e-12
         st_in = torch.stack([Xs.double().mean(1), 1 / torch.sqrt(Xs.double().var(1, unbiased=False) + eps)], 1).float().contiguous()
@@ -349,11 +380,11 @@ def test_production_split_epilogue_is_bit_exact(lib, dt, K):
                                            x16_f.data_ptr(), stats_ref.data_ptr(), part.data_ptr(), _stream()) == 0
         torch.cuda.synchronize()
         want_hi = out32.to(t16)
-        want_lo = (out32 - want_hi.float()).half()
+        want_lo = _lo8_encode(out32 - want_hi.float()).view(torch.uint8) if lo8 else (out32 - want_hi.float()).half().view(torch.int16)
         assert torch.equal(want_hi, x16_f)
         del R, x16_f
         for run in range(4):
-            x16, lo_out = hi.clone(), lo.clone()                 # in place: the epilogue reads and overwrites the same rows
+            x16, lo_out = hi.clone(), (_lo8_to_device_layout(lo_in8) if lo8 else lo.clone())   # in place: the epilogue reads and overwrites the same rows
             stats = torch.empty(M, 2, device="cuda")
             assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), x16.data_ptr(), lo_out.data_ptr(), st_in.data_ptr(),
                                               gamma.data_ptr(), beta.data_ptr(), M, N, K, eps, x16.data_ptr(), lo_out.data_ptr(),
@@ -361,11 +392,14 @@ def test_production_split_epilogue_is_bit_exact(lib, dt, K):
             torch.cuda.synchronize()
             bad = (x16.view(torch.int16) != want_hi.view(torch.int16)).nonzero()
             assert len(bad) == 0, f"run {run}: {len(bad)} hi elements differ from the fp32-stream epilogue, first {bad[:4].tolist()}"
-            bad = (lo_out.view(torch.int16) != want_lo.view(torch.int16)).nonzero()
+            if lo8:
+                lo_out = _lo8_from_device_layout(lo_out, M, N)
+            bad = (lo_out.view(want_lo.dtype) != want_lo).nonzero()
             assert len(bad) == 0, f"run {run}: {len(bad)} lo elements differ, first {bad[:4].tolist()}"
             assert torch.allclose(stats, stats_ref, rtol=1e-6, atol=1e-6)
     finally:
         lib.rr_set_op_dtype(0)
+        lib.rr_set_tuning(b"resid_lo8", -1)
 
 
 @pytest.mark.parametrize("rows,cols", [(1, 128), (7, 768), (1000, 768), (33, 1024), (5, 64)])
@@ -703,17 +737,20 @@ def test_folded_layernorm_halves(lib, M, N, K):
         assert (o2.float() - ln).abs().max().item() < 0.06
 
 
+@pytest.mark.parametrize("lo8", [0, 1])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("with_ln,in_place", [(False, False), (True, True)])
-def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place):
+def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place, lo8):
     """The residual epilogue on the split stream (rr_op_gemm_resid_split): residual rows as hi (operand type) + lo (fp16),
     optionally LayerNormed on the fly, output rows as (x16, lo) + statistics — against the fp32-stream epilogue
     (rr_op_gemm_resid_lnprep) fed the SAME residual values.  x16 must be bit-identical, hi + lo must reproduce the fp32
     rows to 2^-20 relative (fp16 operands: 2^-22), the statistics must agree, and the in-place form (what the forward
-    does) must equal the out-of-place one.  130 048 x 768 = 1 524 tiles: the persistent ring kernel; ragged last row tile."""
+    does) must equal the out-of-place one.  130 048 x 768 = 1 524 tiles: the persistent ring kernel; ragged last row tile.
+    lo8 = 1 ("resid_lo8"): lo as e5m2 bytes of (x - hi) * 16 — hi + lo then reproduces the fp32 rows to 2^-14 (fp16 hi) / 2^-11
+    (bf16 hi) of the element's binade: three significant bits of a lo that is at most half an ulp of hi."""
     M, N, K = 130_048 - 77, 768, 128
     t16 = torch.float16 if dt else torch.bfloat16
-    assert lib.rr_set_op_dtype(dt) == 0
+    assert lib.rr_set_op_dtype(dt) == 0 and lib.rr_set_tuning(b"resid_lo8", lo8) == 0
     try:
         g = torch.Generator().manual_seed(17 + dt)
         A = torch.randn(M, K, generator=g).to(t16).cuda()
@@ -721,9 +758,10 @@ def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place):
         b = torch.randn(N, generator=g).cuda()
         X = (torch.randn(M, N, generator=g) * 3 + 0.5).cuda()                   # previous sublayer's pre-LayerNorm rows
         hi = X.to(t16)
-        lo = (X - hi.float()).half()
-        Xs = hi.float() + lo.float()                                             # what the split stream carries
-        assert ((Xs - X).abs() <= X.abs() * 2.0 ** (-19 if dt == 0 else -21) + 1e-7).all()
+        lo = _lo8_encode(X - hi.float()) if lo8 else (X - hi.float()).half()
+        Xs = hi.float() + (_lo8_decode(lo) if lo8 else lo.float())               # what the split stream carries
+        rel = 2.0 ** ((-11 if dt == 0 else -14) if lo8 else (-19 if dt == 0 else -21))
+        assert ((Xs - X).abs() <= X.abs() * rel + (5e-7 if lo8 else 1e-7)).all()
         eps = 1e-12
         nparts = (N + 127) // 128
         st_in = gamma = beta = None
@@ -740,12 +778,13 @@ def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place):
         assert lib.rr_op_gemm_resid_lnprep(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.contiguous().data_ptr(), M, N, K, eps,
                                            out32.data_ptr(), x16_ref.data_ptr(), stats_ref.data_ptr(), part.data_ptr(), _stream()) == 0
         # split-stream epilogue
+        lo_dev = _lo8_to_device_layout(lo) if lo8 else lo
         if in_place:
-            x16, lo_out = hi.clone(), lo.clone()
+            x16, lo_out = hi.clone(), lo_dev.clone()
             hi_in, lo_in = x16, lo_out
         else:
-            x16, lo_out = torch.empty_like(hi), torch.empty_like(lo)
-            hi_in, lo_in = hi, lo
+            x16, lo_out = torch.empty_like(hi), torch.empty_like(lo_dev)
+            hi_in, lo_in = hi, lo_dev
         stats = torch.empty(M, 2, device="cuda")
         P = lambda t: t.data_ptr() if t is not None else 0
         assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), hi_in.data_ptr(), lo_in.data_ptr(), P(st_in),
@@ -757,12 +796,12 @@ def test_split_residual_stream_epilogue(lib, dt, with_ln, in_place):
             assert (dx <= x16_ref.float().abs() * 2.0 ** (-7 if dt == 0 else -10) + 4e-6).all() and (dx > 0).float().mean().item() < 2e-3
         else:
             assert torch.equal(x16, x16_ref)
-        got = x16.float() + lo_out.float()
-        rel = 2.0 ** (-19 if dt == 0 else -21)
-        assert ((got - out32).abs() <= out32.abs() * rel + (2e-6 if with_ln else 2e-7)).all(), (got - out32).abs().max().item()
+        got = x16.float() + (_lo8_decode(_lo8_from_device_layout(lo_out, M, N)) if lo8 else lo_out.float())
+        assert ((got - out32).abs() <= out32.abs() * rel + (2e-6 if with_ln else 2e-7) + (5e-7 if lo8 else 0.0)).all(), (got - out32).abs().max().item()
         assert torch.allclose(stats, stats_ref, rtol=1e-6, atol=1e-6)
         # shapes the ring kernel does not run are refused, not silently computed some other way
-        assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), hi.data_ptr(), lo.data_ptr(), 0, 0, 0, 512, N, K,
+        assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), hi.data_ptr(), lo_dev.data_ptr(), 0, 0, 0, 512, N, K,
                                           eps, x16.data_ptr(), lo_out.data_ptr(), stats.data_ptr(), part.data_ptr(), _stream()) == -4
     finally:
         lib.rr_set_op_dtype(0)
+        lib.rr_set_tuning(b"resid_lo8", -1)
