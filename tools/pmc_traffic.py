@@ -78,15 +78,22 @@ per_kernel = {k: {"launches": nfk[k], "read_gb_per_launch": round(2.0 * fk[k] * 
               for k in sorted(fk, key=lambda k: -fk[k]) if 2.0 * fk[k] * 1024.0 > 1e8}
 # the split-residual kernel by SHAPE.  Which parity is FFN-down is read off the data (it reads the 2.5 GB FFN
 # intermediate, attention-out the 0.63 GB attention output); the same parity then labels the WRITE_SIZE pass (same dispatch order).
-RESID = "gemm_kernel_hp<4, 1, 3"
+# (<4, 1, 11, ...>: the same epilogue with the 8-bit lo half, the default of fp16 handles since round 5; <4, 1, 3, ...>: the fp16 lo)
+RESID, LO_B = "gemm_kernel_hp<4, 1, 11", 1.0
 fe, fo = load_by_shape(fd, "FETCH_SIZE", RESID)
+if not fe:
+    RESID, LO_B = "gemm_kernel_hp<4, 1, 3", 2.0
+    fe, fo = load_by_shape(fd, "FETCH_SIZE", RESID)
 we, wo = load_by_shape(wd, "WRITE_SIZE", RESID)
+ROWS_GB = 0.629          # 409 600 rows x 768 columns x 2 bytes
 per_shape = {}
 if fe and fo:
     mean = lambda v: sum(v) / max(1, len(v))
     even_is_down = mean(fe) > mean(fo)
-    for label, fr, wr_, alg_r, alg_w in (("FFN-down (N 768, K 3072)", fe if even_is_down else fo, we if even_is_down else wo, 3.78, 1.28),
-                                         ("attention-out (N 768, K 768)", fo if even_is_down else fe, wo if even_is_down else we, 1.89, 1.28)):
+    # algorithmic bytes: A rows (2.52 / 0.63 GB) + residual hi + lo in; hi + lo + 8-byte statistics partials out
+    resid_in, rows_out = ROWS_GB * (1.0 + LO_B / 2.0), ROWS_GB * (1.0 + LO_B / 2.0) + 0.02
+    for label, fr, wr_, alg_r, alg_w in (("FFN-down (N 768, K 3072)", fe if even_is_down else fo, we if even_is_down else wo, round(4 * ROWS_GB + resid_in, 2), round(rows_out, 2)),
+                                         ("attention-out (N 768, K 768)", fo if even_is_down else fe, wo if even_is_down else we, round(ROWS_GB + resid_in, 2), round(rows_out, 2))):
         per_shape[RESID + ", 0, false> " + label] = {"launches": len(fr), "read_gb_per_launch": round(2.0 * mean(fr) * 1024.0 / 1e9, 4),
                                                      "write_gb_per_launch": round(mean(wr_) * 1024.0 / 1e9, 4),
                                                      "algorithmic_read_gb": alg_r, "algorithmic_write_gb": alg_w}
