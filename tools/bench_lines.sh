@@ -5,6 +5,7 @@ tag=$1
 o=gpurun_out
 X="--no-cpu-baseline --no-e2e"
 python bench.py > $o/${tag}_c3_bench.json.log 2>/dev/null; echo c3 done
+python bench.py --tuning resid_lo8=0 $X --no-alt-dtype > $o/${tag}_c3_lo16_bench.json.log 2>/dev/null; echo c3 with the fp16 lo half done
 python bench.py --workload c4 $X > $o/${tag}_c4_bench.json.log 2>/dev/null; echo c4 done
 python bench.py --workload L $X > $o/${tag}_L_bench.json.log 2>/dev/null; echo L done
 python bench.py --workload c5 $X > $o/${tag}_c5_16bit_bench.json.log 2>/dev/null; echo c5 done
