@@ -925,7 +925,8 @@ int run_layer(rr_model* m, hipStream_t st, const LayerW& L, int batch, int Tseq,
     // Split residual stream (rr_gemm_split_ok: the persistent ring kernel runs these shapes): a pre-LayerNorm row lives
     // as hi = the 16-bit operand rows in w.h16 + lo = fp16(x - hi) in the memory of w.pre, both updated in place by the
     // residual epilogues (an element is read and written by the same thread), instead of a third, fp32 copy: 8 instead of
-    // 10 bytes per element through the two HBM-bound epilogues of a layer.  The last layer of a stack writes fp32 rows
+    // 10 bytes per element through the two HBM-bound epilogues of a layer — 6 with "resid_lo8" (lo as e5m2 bytes in the same
+    // memory, rows paired for 16-byte accesses: rr_common.h lo8_pair_offset), the default of fp16 handles.  The last layer of a stack writes fp32 rows
     // (w.pre2) for the LayerNorm kernel that materialises the stack's output.
     const bool split = opt_of(m, RR_OPT_RESID_SPLIT) && rr_gemm_split_ok(rows, Hd);
     bf16_t* const lo16 = (bf16_t*)w.pre;          // (with "resid_lo8": rows of Hd BYTES in the same memory)
