@@ -737,6 +737,74 @@ def test_folded_layernorm_halves(lib, M, N, K):
         assert (o2.float() - ln).abs().max().item() < 0.06
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_eight_bit_lo_half_at_extreme_magnitudes(lib, dt):
+    """The 8-bit lo half where its e5m2 code leaves the comfortable range: residual columns of magnitude 1e3 and 1e-4 beside
+    ordinary ones, output columns of magnitude 2e4 (lo * 16 up to 256) and 1e-5 (lo * 16 below the smallest e5m2 subnormal:
+    the code underflows to zero, i.e. the element keeps hi's precision, an absolute error below 2^-21).  Same bit-exact
+    construction as test_production_split_epilogue_is_bit_exact: the bytes must be torch's round-to-nearest-even e5m2
+    conversion of the exact difference — subnormals included — and the decoded rows must reproduce the fp32 rows to three
+    significant bits of lo or 2^-21 absolute."""
+    M, N, K = 512 * 256 - 31, 768, 128
+    t16 = torch.float16 if dt else torch.bfloat16
+    assert lib.rr_set_op_dtype(dt) == 0 and lib.rr_set_tuning(b"resid_lo8", 1) == 0
+    try:
+        g = torch.Generator().manual_seed(91 + dt)
+        A = torch.randn(M, K, generator=g).to(t16).cuda()
+        Wf = torch.randn(N, K, generator=g) * 0.05
+        Wf[128:192] = 0.0                                           # columns 128..191: no GEMM term
+        W = Wf.to(t16).cuda()
+        b = torch.randn(N, generator=g)
+        b[128:192] *= 1e-5                                           # ... and a bias of 1e-5: outputs the e5m2 code of lo cannot reach
+        b[192:256] = 2.0e4 * (1.0 + 0.01 * torch.randn(64, generator=g))        # outputs near 2e4: lo * 16 up to 256
+        b = b.cuda()
+        X = torch.randn(M, N, generator=g) * 3 + 0.5
+        X[:, 0:64] *= 1.0e3
+        X[:, 64:128] *= 1.0e-4
+        X = X.cuda()
+        hi = X.to(t16)
+        lo_in8 = _lo8_encode(X - hi.float())
+        lo = _lo8_decode(lo_in8).half()
+        assert torch.equal(lo.float(), _lo8_decode(lo_in8))          # an e5m2 value / 16 is exact in fp16, subnormals included
+        Xs = hi.float() + lo.float()
+        assert ((Xs - X).abs() <= X.abs() * 2.0 ** (-11 if dt == 0 else -14) + 2.0 ** -21).all()
+        eps = 1e-12
+        st_in = torch.stack([Xs.double().mean(1), 1 / torch.sqrt(Xs.double().var(1, unbiased=False) + eps)], 1).float().contiguous()
+        gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.05 * torch.randn(N, generator=g)).cuda()
+        gamma[128:192] = 0.0
+        beta[128:192] = 0.0
+        del X, Xs
+        nparts = (N + 127) // 128
+        R = torch.empty(M, N, device="cuda")
+        assert lib.rr_op_split_residual_value(hi.data_ptr(), lo.data_ptr(), st_in.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, N,
+                                              R.data_ptr(), _stream()) == 0
+        out32 = torch.empty(M, N, device="cuda")
+        x16_f, stats_ref, part = torch.empty(M, N, device="cuda", dtype=t16), torch.empty(M, 2, device="cuda"), torch.empty(M, nparts, 2, device="cuda")
+        assert lib.rr_op_gemm_resid_lnprep(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), M, N, K, eps, out32.data_ptr(),
+                                           x16_f.data_ptr(), stats_ref.data_ptr(), part.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        assert out32[:, 128:192].abs().max().item() < 1e-4 and out32[:, 192:256].abs().min().item() > 1.5e4
+        want_hi = out32.to(t16)
+        want_lo = _lo8_encode(out32 - want_hi.float()).view(torch.uint8)
+        del R, x16_f
+        x16, lo_out = hi.clone(), _lo8_to_device_layout(lo_in8)
+        stats = torch.empty(M, 2, device="cuda")
+        assert lib.rr_op_gemm_resid_split(A.data_ptr(), W.data_ptr(), b.data_ptr(), x16.data_ptr(), lo_out.data_ptr(), st_in.data_ptr(),
+                                          gamma.data_ptr(), beta.data_ptr(), M, N, K, eps, x16.data_ptr(), lo_out.data_ptr(),
+                                          stats.data_ptr(), part.data_ptr(), _stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(x16.view(torch.int16), want_hi.view(torch.int16))
+        got_lo = _lo8_from_device_layout(lo_out, M, N).view(torch.uint8)
+        bad = (got_lo != want_lo).nonzero()
+        assert len(bad) == 0, f"{len(bad)} lo bytes differ from torch's e5m2 rounding, first {bad[:4].tolist()}: " \
+                              f"{[(int(got_lo[i, j]), int(want_lo[i, j]), float(out32[i, j])) for i, j in bad[:4].tolist()]}"
+        got = x16.float() + _lo8_decode(got_lo.view(torch.float8_e5m2))
+        assert ((got - out32).abs() <= out32.abs() * 2.0 ** (-11 if dt == 0 else -14) + 2.0 ** -21).all()
+    finally:
+        lib.rr_set_op_dtype(0)
+        lib.rr_set_tuning(b"resid_lo8", -1)
+
+
 @pytest.mark.parametrize("lo8", [0, 1])
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("with_ln,in_place", [(False, False), (True, True)])
