@@ -142,6 +142,7 @@ struct LayerW {
 struct ProfEvent {
   hipEvent_t a, b;
   int kclass;
+  int start;      // >= 0: this launch starts where launch `start` of the pool ended (its `b` event; `a` was not recorded), -1: at its own `a`
 };
 
 }  // namespace
@@ -210,6 +211,12 @@ struct rr_model {
   bool profiling = false;
   std::vector<ProfEvent> ev_pool;
   size_t ev_used = 0;
+  // Chained events: a launch that directly follows another profiled launch on the same stream takes that launch's end event as
+  // its start — one hipEventRecord per launch instead of two (an event costs the step ~3 us of idle queue: 274 of them were
+  // 0.95 % of the c3 step, gpurun log in docs/rounds/r05.md).  Anything else the library enqueues in between (RR_HIP: copies,
+  // memsets) and every new API call break the chain, so foreign work is never billed to a kernel class.
+  int prof_chain = -1;
+  hipStream_t prof_chain_st = nullptr;
   rr_profile prof{};
 };
 
@@ -230,6 +237,7 @@ int fail(rr_model* m, int code, const char* fmt, ...) noexcept {
 // message kept for rr_last_error().
 template <class R = int, class F>
 R guarded(rr_model* m, F&& body) noexcept {
+  if (m) m->prof_chain = -1;                       // events never chain across API calls (the caller may have used the stream)
   try {
     return body();
   } catch (const std::bad_alloc&) {
@@ -243,6 +251,7 @@ R guarded(rr_model* m, F&& body) noexcept {
 
 #define RR_HIP(m, call)                                                                        \
   do {                                                                                         \
+    if (m) (m)->prof_chain = -1;                /* whatever this enqueues is not part of the next profiled launch */ \
     hipError_t e_ = (call);                                                                    \
     if (e_ != hipSuccess)                                                                      \
       return fail(m, e_ == hipErrorOutOfMemory ? RR_ERR_OOM : RR_ERR_HIP, "%s failed: %s", #call, \
@@ -260,15 +269,20 @@ struct Prof {
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
       m->ev_pool.push_back(e);
     }
+    const bool chained = m->prof_chain >= 0 && m->prof_chain_st == st && (size_t)m->prof_chain + 1 == m->ev_used;
     idx = (int)m->ev_used++;
     m->ev_pool[idx].kclass = kclass;
+    m->ev_pool[idx].start = chained ? m->prof_chain : -1;
     m->prof.launches[kclass] += 1;
     m->prof.flops[kclass] += flops;
     m->prof.bytes[kclass] += bytes;
-    (void)hipEventRecord(m->ev_pool[idx].a, st);
+    if (!chained) (void)hipEventRecord(m->ev_pool[idx].a, st);
   }
   ~Prof() {
-    if (idx >= 0) (void)hipEventRecord(m->ev_pool[idx].b, st);
+    if (idx < 0) return;
+    const bool ok = hipEventRecord(m->ev_pool[idx].b, st) == hipSuccess;
+    m->prof_chain = ok ? idx : -1;
+    m->prof_chain_st = st;
   }
 };
 
@@ -1941,7 +1955,7 @@ static int rr_get_profile_impl(rr_handle h, rr_profile* out, int reset) {
     ProfEvent& e = h->ev_pool[i];
     RR_HIP(h, hipEventSynchronize(e.b));
     float ms = 0.f;
-    RR_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+    RR_HIP(h, hipEventElapsedTime(&ms, e.start >= 0 ? h->ev_pool[e.start].b : e.a, e.b));
     h->prof.ms[e.kclass] += ms;
   }
   h->ev_used = 0;

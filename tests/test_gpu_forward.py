@@ -835,3 +835,42 @@ def test_degenerate_lists_and_pairs(loss):
         assert order == [O.rank_descending_stable(x) for x in got.view(Bq, K).tolist()]
         if K >= 4:
             assert got[K + 2].item() == got[K + 1].item() and order[1].index(1) < order[1].index(2)
+
+
+def test_profile_of_a_forward_accounts_for_its_device_time():
+    """rr_set_profiling / rr_get_profile (what bench.py's roofline and kernel_ms_per_step are read from): one event per launch,
+    chained — a launch that directly follows another profiled launch on the stream starts where that one ended, so the
+    classes' times add up to the device time of the forward: never more than the host-timed forward, and (nothing else
+    runs on the stream) most of it.  A second forward after a reset reports the same launches; other stream work between two
+    API calls is not billed to any class."""
+    import time
+    g = load_golden("c2")
+    cfg = g["cfg"]
+    w = O.make_weights(cfg, seed=0, vision=False)
+    ids, am, tt, _ = golden_inputs(g)
+    args = (ids.cuda(), am.cuda(), tt.cuda(), g["Bq"], g["K"], None, None, None)
+    eng = _engine(cfg, False, w, "fp16")
+    for _ in range(2):
+        eng.forward_ids(*args)
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    eng.get_profile(reset=True)
+    t0 = time.perf_counter()
+    eng.forward_ids(*args)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    p1 = eng.get_profile(reset=True)
+    total = sum(v["ms"] for v in p1.values())
+    launches = {k: v["launches"] for k, v in p1.items()}
+    assert launches["gemm"] > 0 and launches["attention"] > 0 and all(v["ms"] >= 0.0 for v in p1.values())
+    assert 0.3 * wall_ms < total <= 1.02 * wall_ms, (total, wall_ms)
+    # foreign work on the stream between two calls: its time must not show up in the next forward's classes
+    x = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):
+        x = x @ x * 1e-3
+    eng.forward_ids(*args)
+    torch.cuda.synchronize()
+    p2 = eng.get_profile(reset=True)
+    assert {k: v["launches"] for k, v in p2.items()} == launches
+    assert sum(v["ms"] for v in p2.values()) < 2.0 * total + 0.5
+    eng.set_profiling(False)
