@@ -128,7 +128,9 @@ int rr_set_gemm_variant(int variant);
  * percent of a tile period), "persistent_gemm" (1), "gemm_ring_min_tiles" (128: smallest problem, in 256 x 256 tiles, on the
  * persistent ring), "m_alternate" (1: consecutive large launches of the layer chain walk the rows in opposite directions, so that
  * a consumer starts on the rows its producer wrote last; results bit-identical either way),
- * "attn_prio" (1).  Not thread-safe against running forwards; never needed on the product path. */
+ * "attn_prio" (1).  "resid_lo8": -1 (the built-in default) = by operand type (1 for fp16, 0 for bf16), 0 / 1 = for every handle that has not
+ * pinned it; the environment variable RR_RESID_LO8 = 0 | 1, read once at load, replaces the built-in -1 (lets an unmodified test
+ * run take either form).  Not thread-safe against running forwards; never needed on the product path. */
 int rr_set_tuning(const char* key, int value);
 int rr_set_op_dtype(int dt);          /* operand dtype (0 bf16 / 1 fp16) of the stand-alone rr_op_* entry points */
 int rr_set_gemm_stamps(void* device_buf);
